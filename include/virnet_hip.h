@@ -1,0 +1,159 @@
+/*
+ * virnet_hip.h -- C ABI of the MI355X (gfx950) kernels behind VIRNet's convolutional forward.
+ *
+ * The reference (zsyOAOA/VIRNet) is pure Python on PyTorch: it has no FFI, plugin or operator
+ * registry.  Its boundary for this path is the nn.Module surface of networks/VIRNet.py
+ * (VIRAttResUNet.forward :42-46, VIRAttResUNetSR.forward :80-97) and the arithmetic sits in
+ * torch.nn.functional call sites.  Each entry point below therefore cites the reference CALL SITE
+ * (file:line under /root/reference) whose arithmetic it replaces; the modules under virnet_amd/networks/ is the
+ * Python host side that mirrors the reference classes and binds these symbols through ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise; no torch types cross the ABI
+ *   - activations between kernels are NHWC fp32 ("pixel records"), channel count a multiple of 16
+ *   - images enter and leave as NCHW fp32 exactly as the reference modules receive/return them
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ *   - return value: 0 on success, non-zero on error; virnet_last_error() gives the message
+ */
+#ifndef VIRNET_HIP_H
+#define VIRNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIRNET_ABI_VERSION 1
+
+int virnet_abi_version(void);
+const char* virnet_last_error(void);
+/* number of visible HIP devices, or -1 when the runtime cannot be initialised */
+int virnet_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight packing.  Reference layouts in, MFMA-fragment ("stage") layout out.
+ *   kind 0: nn.Conv2d weight  [Cout][Cin][KS][KS]            (AttResUNet.py:43,46,67,117,139; DnCNN.py:22-29;
+ *                                                             KNet.py:32,34,49)
+ *   kind 1: nn.ConvTranspose2d(k=2,s=2) weight [Cin][Cout][2][2] (AttResUNet.py:80), packed as the equivalent
+ *           1x1 GEMM to N = 4*Cout columns ordered (a*2+b)*Cout + co
+ * `cin_pad` (multiple of 16) and `n_pad` (multiple of 32*nrep) give the zero-padded GEMM extents; `nrep` is the
+ * number of 32-column blocks one workgroup owns (see virnet_conv_plan).
+ * ---------------------------------------------------------------------------------------------- */
+size_t virnet_packed_weight_floats(int ks, int cin_pad, int n_pad);
+int virnet_pack_weight(const float* w, int kind, int cout, int cin, int ks, int cin_pad, int n_pad, int nrep,
+                       float* packed, void* stream);
+
+/* Tile plan chosen by the library for one conv shape (so the host can pack with the right nrep). */
+typedef struct virnet_conv_plan {
+  int nrep;    /* 32-column blocks per workgroup (GEMM-N block = 32*nrep) */
+  int n_pad;   /* padded GEMM-N extent */
+  int cin_pad; /* padded Cin (multiple of 16) */
+} virnet_conv_plan;
+/* ks in {1,3}; stride in {1,2}; gemm_n = Cout (conv) or 4*Cout (transposed conv) */
+int virnet_conv_get_plan(int ks, int stride, int cin, int gemm_n, virnet_conv_plan* plan);
+
+/* ------------------------------------------------------------------------------------------------
+ * The MFMA implicit-GEMM convolution (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces: AttResBlock.conv1/conv2 (AttResUNet.py:55,58 with the residual add :59), DownBlock.downsampler
+ * (AttResUNet.py:67), UpBlock.upsampler + bridge add (AttResUNet.py:84-87), AttResUNet.head/tail (:153-155,:173),
+ * DnCNN.conv1/mid_layer/conv_last (DnCNN.py:38-41), RB_Layer convs and KernelNet.tail conv (KNet.py:32-34,49).
+ * ---------------------------------------------------------------------------------------------- */
+enum { VIRNET_EPI_NHWC = 0, VIRNET_EPI_CONVT = 1, VIRNET_EPI_NCHW = 2 };
+enum { VIRNET_NCHW_PLAIN = 0, VIRNET_NCHW_ADD = 1, VIRNET_NCHW_EXPCLAMP = 2 };
+
+typedef struct virnet_conv_desc {
+  const float* x;      /* NHWC [n][h][w][cin_pad] */
+  const float* wpack;  /* from virnet_pack_weight */
+  const float* bias;   /* [cout] or NULL */
+  const float* res;    /* EPI_NHWC: NHWC [n][oh][ow][cout] residual (AttResUNet.py:59) or NULL
+                          EPI_CONVT: NHWC [n][2h][2w][cout] bridge (AttResUNet.py:87) or NULL
+                          EPI_NCHW : NCHW [n][cout][crop_h][crop_w] (the `+ x_in` of AttResUNet.py:173) or NULL */
+  const float* mul;    /* [n][cout] SFT scale for the activated copy (AttResUNet.py:54-58) or NULL (=1) */
+  const float* add;    /* [n][cout] SFT shift or NULL (=0) */
+  float* y_raw;        /* conv + bias (+res); NULL = not stored */
+  float* y_act;        /* leaky_relu(y_raw*mul+add, slope); NULL = not stored (EPI_NHWC / EPI_CONVT only) */
+  int n, h, w;         /* input batch / spatial size */
+  int cin_pad;         /* channels of x (multiple of 16) */
+  int cout;            /* real output channels (EPI_CONVT: channels of the up-sampled tensor) */
+  int n_pad;           /* padded GEMM-N extent used when packing */
+  int nrep;            /* from the plan used when packing */
+  int ks, stride;      /* {3,1}: s1 or s2, pad 1 ; {1,1}: pointwise */
+  int epi;             /* VIRNET_EPI_* */
+  int nchw_op;         /* VIRNET_NCHW_* (EPI_NCHW only) */
+  int crop_h, crop_w;  /* EPI_NCHW: stored extent (<= oh, ow) */
+  int res_sf;          /* EPI_NCHW + VIRNET_NCHW_ADD: res is [n][cout][crop_h/res_sf][crop_w/res_sf] and is read through a
+                          nearest x res_sf up-sampling (the x_up of VIRNet.py:83 added at AttResUNet.py:173); 0/1 = none */
+  float slope;         /* LeakyReLU slope of y_act */
+  float clamp_lo, clamp_hi; /* VIRNET_NCHW_EXPCLAMP: y = exp(clamp(v, lo, hi))  (VIRNet.py:43) */
+} virnet_conv_desc;
+
+int virnet_conv_mfma(const virnet_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Image entry: NCHW -> 16-channel NHWC pixel records, fusing
+ *   - the nearest x`sf` up-sampling of VIRNet.py:83 (sf = 1 for denoising),
+ *   - the bottom/right reflect pad of utils/util_net.py:20-25 (hp >= h*sf, wp >= w*sf),
+ *   - the channel concat of AttResUNet.py:153 with per-image vectors (kinfo / sqrt(sigma) repeated, VIRNet.py:89,92)
+ *     and/or a per-pixel map (sigma map; VIRNet.py:44 sqrt, VIRNet.py:94 nearest x msf).
+ * Channel order: [c0 image channels][ev vector channels][em map channels][zeros up to 16].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct virnet_pack_desc {
+  const float* x;    /* NCHW [n][c0][h][w] */
+  const float* vec;  /* [n][ev] or NULL */
+  const float* map;  /* NCHW [n][em][mh][mw] or NULL; source pixel = (reflect(y)/msf, reflect(x)/msf) */
+  float* out;        /* NHWC [n][hp][wp][16] */
+  int n, c0, h, w, sf;
+  int ev;
+  int em, mh, mw, msf, map_sqrt;
+  int hp, wp;
+} virnet_pack_desc;
+int virnet_pack_input(const virnet_pack_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KNet pieces (networks/KNet.py) and the SFT generator (networks/AttResUNet.py:11-32).  Small, latency-bound kernels.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* KernelNet.head: Conv2d(cin -> cout, k=9, s=4, p=4, bias=False) (KNet.py:45,53).  x NCHW [n][cin][h][w], w OIHW,
+ * out NHWC [n][oh][ow][cout] with oh = (h-1)/4+1, ow = (w-1)/4+1; cout a multiple of 64. */
+int virnet_conv_head_s4(const float* x, const float* w, float* out, int n, int cin, int h, int w_, int cout, void* stream);
+
+/* Global average pool of a planar tensor [n][c][h][w] -> out[n][c], with the finishing op of its call site:
+ *   VIRNET_GAP_MEAN      mean                                  (DnCNN.py:31,42)
+ *   VIRNET_GAP_EXPCLAMP  exp(clamp(mean, lo, hi))              (VIRNet.py:81 on the pooled SNet output)
+ *   VIRNET_GAP_KINFO     channels 0..c-2 exp(clamp(mean, lo, hi)), channel c-1 tanh(mean)   (KNet.py:50,56-59) */
+enum { VIRNET_GAP_MEAN = 0, VIRNET_GAP_EXPCLAMP = 1, VIRNET_GAP_KINFO = 2 };
+int virnet_gap_nchw(const float* x, float* out, int n, int c, int h, int w, int finish, float lo, float hi, void* stream);
+
+/* CALayer gate (KNet.py:15-25): gate[n][c] = sigmoid(W2 lrelu0.2(W1 mean_hw(x[n]) + b1) + b2); x NHWC [n][h][w][c];
+ * W1 [cr][c], W2 [c][cr] (the 1x1 conv weights); c <= 256 and a divisor of 256. */
+int virnet_ca_gate(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                   int n, int h, int w, int c, int cr, void* stream);
+
+/* RB_Layer tail (KNet.py:26,38): out = hcv * gate[n][c] + skip, all NHWC [n][h][w][c], c % 4 == 0. */
+int virnet_scale_add(const float* hcv, const float* gate, const float* skip, float* out, int n, int hw, int c, void* stream);
+
+/* AttLayer weights (AttResUNet.py:18-25), all 1x1 convs stored [cout][cin]. */
+typedef struct virnet_sft_weights {
+  const float *w1, *b1;   /* [nf1][e]   */
+  const float *w2, *b2;   /* [nf2][nf1] */
+  const float *wm, *bm;   /* [nf][nf2]  mul_conv (sigmoid) */
+  const float *wa, *ba;   /* [nf][nf2]  add_conv */
+  int e, nf1, nf2, nf;
+} virnet_sft_weights;
+
+/* Spatially constant conditioning: mul[n][nf], add[n][nf] from vec[n][e] (AttLayer.forward, AttResUNet.py:27-32). */
+int virnet_sft_vec(const float* vec, const virnet_sft_weights* wt, float* mul, float* add, int n, void* stream);
+
+/* Per-pixel conditioning: act = lrelu0.2(raw * mul(e) + add(e)) (AttResUNet.py:54-58) where e = channels
+ * [chan0, chan0+wt->e) of the full-resolution 16-channel records rec[n][hp][wp][16] sampled at (y*step, x*step)
+ * -- the nearest resize of AttResUNet.py:168.  raw/act NHWC [n][h][w][nf], hp = h*step, wp = w*step. */
+int virnet_sft_apply(const float* raw, const float* rec, const virnet_sft_weights* wt, float* act, int n, int h, int w,
+                     int step, int chan0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIRNET_HIP_H */

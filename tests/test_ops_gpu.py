@@ -1,0 +1,224 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (oracle/cpu_ref.py) on the same seeded inputs.
+
+Tolerance: the contract is 1e-3 max-abs fp32 (BASELINE.json north_star); the fp32 MFMA path differs from the oracle only
+by re-association, so the tests hold it to 2e-5 on O(1) data (about 20x the measured noise floor, 50x inside the contract).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+from virnet_amd import _native as nat
+from virnet_amd import ops
+from virnet_amd.networks.AttResUNet import AttLayer
+from virnet_amd.networks.params import ConvParam
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = np.random.Generator(np.random.Philox(key=[seed, int(np.prod(shape)) & 0xFFFFFFFF]))
+    return torch.from_numpy((g.random(size=shape, dtype=np.float32) * (hi - lo) + lo).astype(np.float32))
+
+
+def nhwc(t):  # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC cuda -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def maxerr(a, b):
+    return float((a - b).abs().max())
+
+
+def make_conv(cin, cout, ks=3, stride=1, transposed=False, seed=1):
+    cp = ConvParam(cin, cout, ks, transposed=transposed, stride=stride)
+    with torch.no_grad():
+        fan = cp.weight[0].numel() if not transposed else cin * ks * ks
+        cp.weight.copy_(rnd(*cp.weight.shape, seed=seed) * (3.0 / fan) ** 0.5)
+        cp.bias.copy_(rnd(cout, seed=seed + 1) * 0.1)
+    return cp
+
+
+@pytest.mark.parametrize("c,h,w,n", [(64, 12, 20, 2), (96, 17, 33, 2), (160, 9, 40, 1), (192, 8, 32, 2), (224, 7, 11, 1),
+                                      (288, 12, 20, 1), (128, 5, 65, 1), (96, 64, 96, 1), (96, 40, 64, 8)])
+def test_conv3x3_dual_store(c, h, w, n):
+    """AttResBlock conv2 shape: conv + bias + residual -> raw, lrelu(raw*mul+add) -> act (AttResUNet.py:57-59)."""
+    cp = make_conv(c, c)
+    x, res = rnd(n, c, h, w, seed=3), rnd(n, c, h, w, seed=4)
+    mul, add = rnd(n, c, seed=5, lo=0.2, hi=1.0), rnd(n, c, seed=6)
+    raw_ref, act_ref = cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach(), residual=res,
+                                          mul=mul.view(n, c, 1, 1), add=add.view(n, c, 1, 1), slope=0.2)
+    cp.cuda()
+    raw, act = ops.conv_mfma(nhwc(x), cp.packed(), res=nhwc(res), mul=mul.cuda(), add=add.cuda(), want_raw=True,
+                             want_act=True, slope=0.2)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+
+
+def test_conv3x3_act_only_and_cross_channels():
+    """DnCNN mid conv (post-activation, slope 0.25, DnCNN.py:25-28) and a Cin != Cout case."""
+    cp = make_conv(64, 64)
+    x = rnd(2, 64, 15, 18, seed=7)
+    _, act_ref = cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach(), slope=0.25)
+    cp.cuda()
+    raw, act = ops.conv_mfma(nhwc(x), cp.packed(), want_raw=False, want_act=True, slope=0.25)
+    assert raw is None and maxerr(nchw(act), act_ref) <= TOL
+    cp2 = make_conv(32, 96)
+    x2 = rnd(1, 32, 10, 37, seed=8)
+    raw_ref, _ = cpu_ref.conv_fused(x2, cp2.weight.detach(), cp2.bias.detach())
+    cp2.cuda()
+    raw2, _ = ops.conv_mfma(nhwc(x2), cp2.packed())
+    assert maxerr(nchw(raw2), raw_ref) <= TOL
+
+
+def test_zero_padding_is_applied_after_activation():
+    """A constant field: border outputs must see zeros, not lrelu(add) (SURVEY.md 'pad-after-activation trap')."""
+    cp = make_conv(64, 64)
+    x = torch.full((1, 64, 8, 8), -1.0)
+    a = F.leaky_relu(x, 0.2)
+    ref = F.conv2d(a, cp.weight.detach(), cp.bias.detach(), padding=1)
+    cp.cuda()
+    raw, _ = ops.conv_mfma(nhwc(a), cp.packed())
+    assert maxerr(nchw(raw), ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(96, 192, 16, 24, 2), (192, 288, 8, 64, 1), (96, 160, 10, 6, 1), (160, 224, 4, 68, 2),
+                                            (64, 128, 130, 66, 1)])
+def test_downsampler_stride2(cin, cout, h, w, n):
+    """DownBlock.downsampler: Conv2d(k3,s2,p1) on the raw tensor (AttResUNet.py:67,74)."""
+    cp = make_conv(cin, cout, stride=2)
+    x = rnd(n, cin, h, w, seed=9)
+    raw_ref, act_ref = cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach(), stride=2)
+    cp.cuda()
+    raw, act = ops.conv_mfma(nhwc(x), cp.packed(), stride=2, want_raw=True, want_act=True)
+    assert tuple(raw.shape) == (n, h // 2, w // 2, cout)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(192, 96, 9, 20, 2), (288, 192, 8, 8, 1), (224, 160, 5, 33, 1), (160, 96, 6, 7, 2),
+                                            (128, 64, 3, 70, 1)])
+def test_upsampler_convtranspose_bridge(cin, cout, h, w, n):
+    """UpBlock: ConvTranspose2d(k2,s2) + bridge -> raw, lrelu(raw) (AttResUNet.py:80,84-87)."""
+    cp = make_conv(cin, cout, ks=2, stride=2, transposed=True)
+    x, bridge = rnd(n, cin, h, w, seed=10), rnd(n, cout, 2 * h, 2 * w, seed=11)
+    raw_ref, act_ref = cpu_ref.conv_transpose_fused(x, cp.weight.detach(), cp.bias.detach(), bridge)
+    cp.cuda()
+    raw, act = ops.conv_mfma(nhwc(x), cp.packed(), res=nhwc(bridge), want_raw=True, want_act=True)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+
+
+def test_thin_output_epilogues():
+    """tail: conv -> crop -> + x_in (AttResUNet.py:173); SNet last: exp(clamp(.)) (VIRNet.py:43); plain planar store."""
+    cp = make_conv(96, 3)
+    x, xin = rnd(2, 96, 12, 36, seed=12), rnd(2, 3, 10, 33, seed=13)
+    ref = F.conv2d(x, cp.weight.detach(), cp.bias.detach(), padding=1)[..., :10, :33] + xin
+    cp.cuda()
+    out = ops.conv_mfma_nchw(nhwc(x), cp.packed(), (10, 33), op=nat.NCHW_ADD, res=xin.cuda())
+    assert maxerr(out.cpu(), ref) <= TOL
+    # nearest-upsampled residual (VIRNet.py:83 fused): res is the low-resolution image
+    xlr = rnd(2, 3, 6, 18, seed=14)
+    ref2 = F.conv2d(x, cp.weight.detach().cpu(), cp.bias.detach().cpu(), padding=1) + F.interpolate(xlr, scale_factor=2, mode="nearest")
+    out2 = ops.conv_mfma_nchw(nhwc(x), cp.packed(), (12, 36), op=nat.NCHW_ADD, res=xlr.cuda(), res_sf=2)
+    assert maxerr(out2.cpu(), ref2) <= TOL
+    cs = make_conv(64, 1)
+    with torch.no_grad():
+        cs.weight.mul_(4.0)   # push some values past the clamp
+    xs = rnd(1, 64, 9, 40, seed=15, lo=-3, hi=3)
+    v = F.conv2d(xs, cs.weight.detach(), cs.bias.detach(), padding=1)
+    refs = torch.exp(torch.clamp(v, min=-2.0, max=1.5))
+    cs.cuda()
+    outs = ops.conv_mfma_nchw(nhwc(xs), cs.packed(), (9, 40), op=nat.NCHW_EXPCLAMP, clamp=(-2.0, 1.5))
+    assert float((v > 1.5).sum()) > 0 and float((v < -2.0).sum()) > 0
+    assert maxerr(outs.cpu(), refs) <= 5e-6 * float(refs.max())
+    outp = ops.conv_mfma_nchw(nhwc(xs), cs.packed(), (9, 40))
+    assert maxerr(outp.cpu(), v) <= 1e-4   # |v| reaches ~40 here
+
+
+def test_pack_input_reflect_upsample_concat():
+    """Entry kernel vs pad_input / interpolate / cat (util_net.py:20-25, VIRNet.py:83-95, AttResUNet.py:153)."""
+    x, sig = rnd(2, 3, 37, 45, seed=16, lo=0, hi=1), rnd(2, 1, 37, 45, seed=17, lo=0.1, hi=2)
+    ref = cpu_ref.pad_to_multiple(torch.cat([x, sig.sqrt()], 1), 4)
+    out = ops.pack_input(x.cuda(), 40, 48, map_=sig.cuda(), map_sqrt=True)
+    assert tuple(out.shape) == (2, 40, 48, 16)
+    assert maxerr(nchw(out)[:, :4], ref) <= 1e-7 and float(out[..., 4:].abs().max()) == 0.0
+    # SISR: nearest x3, per-image vector repeated, LR sigma map up-sampled x3, pad 27x33 -> 28x36
+    xl, vec, sl = rnd(1, 3, 9, 11, seed=18), rnd(1, 3, seed=19), rnd(1, 1, 9, 11, seed=20, lo=0.1, hi=1)
+    xu = F.interpolate(xl, scale_factor=3, mode="nearest")
+    ex = torch.cat([xu, vec.view(1, 3, 1, 1).repeat(1, 1, 27, 33), F.interpolate(sl.sqrt(), scale_factor=3, mode="nearest")], 1)
+    ref2 = cpu_ref.pad_to_multiple(ex, 4)
+    out2 = ops.pack_input(xl.cuda(), 28, 36, sf=3, vec=vec.cuda(), map_=sl.cuda(), map_sf=3, map_sqrt=True)
+    assert maxerr(nchw(out2)[:, :7], ref2) <= 1e-7
+    with pytest.raises(RuntimeError, match="pad < dim"):   # F.pad reflect contract (util_net.py:24)
+        ops.pack_input(rnd(1, 3, 2, 2).cuda(), 4, 4)
+
+
+def test_knet_pieces():
+    """KernelNet.head 9x9/s4 (KNet.py:45), CALayer gate + scale + skip (KNet.py:15-26,38), pooled finishing ops (KNet.py:56-59)."""
+    w = rnd(64, 3, 9, 9, seed=21) * 0.06
+    x = rnd(2, 3, 21, 30, seed=22, lo=0, hi=1)
+    ref = F.conv2d(x, w, None, stride=4, padding=4)
+    out = ops.conv_head_s4(x.cuda(), w.cuda())
+    assert tuple(out.shape) == (2, 6, 8, 64) and maxerr(nchw(out), ref) <= TOL
+    h, skip = rnd(2, 64, 6, 8, seed=23), rnd(2, 64, 6, 8, seed=24)
+    w1, b1, w2, b2 = rnd(4, 64, 1, 1, seed=25) * 0.2, rnd(4, seed=26) * 0.1, rnd(64, 4, 1, 1, seed=27), rnd(64, seed=28) * 0.1
+    sd = {"ca.body.0.weight": w1, "ca.body.0.bias": b1, "ca.body.2.weight": w2, "ca.body.2.bias": b2}
+    ref_rb = cpu_ref.ca_layer(sd, "ca.", h) + skip
+    gate = ops.ca_gate(nhwc(h), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
+    got = ops.scale_add(nhwc(h), gate, nhwc(skip))
+    assert maxerr(nchw(got), ref_rb) <= 1e-6
+    t = rnd(3, 3, 7, 9, seed=29, lo=-12, hi=3)
+    m = t.mean(dim=(2, 3))
+    refk = torch.cat([torch.exp(torch.clamp(m[:, :2], min=cpu_ref.K_LOG_MIN, max=cpu_ref.K_LOG_MAX)), torch.tanh(m[:, 2:])], 1)
+    assert maxerr(ops.gap_nchw(t.cuda(), ops.GAP_KINFO, (cpu_ref.K_LOG_MIN, cpu_ref.K_LOG_MAX)).cpu(), refk) <= 1e-6
+    assert maxerr(ops.gap_nchw(t.cuda()).cpu(), m) <= 1e-6
+    big = rnd(1, 2, 128, 96, seed=30)
+    assert maxerr(ops.gap_nchw(big.cuda(), ops.GAP_EXPCLAMP, (-1.0, 1.0)).cpu(), torch.exp(big.mean(dim=(2, 3)).clamp(-1, 1))) <= 1e-6
+
+
+@pytest.mark.parametrize("nf,e", [(96, 4), (160, 4), (224, 4), (64, 1)])
+def test_sft_generators(nf, e):
+    """AttLayer (AttResUNet.py:27-32): per-image vector form and per-pixel form with the nearest-resized extra maps (:168)."""
+    att = AttLayer(nf, e)
+    sd = {"a." + k: v.detach() for k, v in att.state_dict().items()}
+    vec = rnd(3, e, seed=31, lo=0, hi=1.5)
+    mul_ref, add_ref = cpu_ref.att_layer(sd, "a.", vec.view(3, e, 1, 1))
+    att.cuda()
+    mul, add = ops.sft_vec(vec.cuda(), att)
+    assert maxerr(mul.cpu(), mul_ref.view(3, nf)) <= 1e-6 and maxerr(add.cpu(), add_ref.view(3, nf)) <= 1e-6
+    # per-pixel: full-res records [x(3) | extra(e)], level 1 (step 2)
+    n, H, W = 2, 12, 20
+    full = rnd(n, 3 + e, H, W, seed=32, lo=0, hi=1)
+    rec = torch.zeros(n, H, W, 16)
+    rec[..., :3 + e] = full.permute(0, 2, 3, 1)
+    raw = rnd(n, nf, H // 2, W // 2, seed=33)
+    ex = F.interpolate(full[:, 3:], (H // 2, W // 2), mode="nearest")
+    m, a = cpu_ref.att_layer(sd, "a.", ex)
+    ref = F.leaky_relu(raw * m + a, 0.2)
+    got = ops.sft_apply(nhwc(raw), rec.cuda(), 3, e, 2, att)
+    assert maxerr(nchw(got), ref) <= 2e-6
+
+
+def test_abi_rejects_bad_shapes():
+    cp = make_conv(96, 96).cuda()
+    with pytest.raises(ValueError, match="channels"):
+        ops.conv_mfma(torch.zeros(1, 8, 8, 64, device="cuda"), cp.packed())
+    with pytest.raises(RuntimeError, match="must be even"):
+        ops.conv_mfma(torch.zeros(1, 7, 8, 96, device="cuda"), make_conv(96, 192, stride=2).cuda().packed(), stride=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv_mfma(torch.zeros(1, 8, 8, 96), cp.packed())
+
+
+def test_repack_follows_parameter_updates():
+    cp = make_conv(64, 64).cuda()
+    x = rnd(1, 64, 8, 32, seed=40)
+    r0, _ = ops.conv_mfma(nhwc(x), cp.packed())
+    with torch.no_grad():
+        cp.weight.mul_(2.0)      # in-place update bumps ._version -> repack
+        cp.bias.zero_()
+    r1, _ = ops.conv_mfma(nhwc(x), cp.packed())
+    ref = F.conv2d(x, cp.weight.detach().cpu(), None, padding=1)
+    assert maxerr(nchw(r1), ref) <= TOL and maxerr(nchw(r0), ref) > 1e-2

@@ -1,0 +1,125 @@
+"""ctypes binding of ``libvirnet_hip.so`` (the C ABI declared in ``include/virnet_hip.h``).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+``import torch`` happens first on purpose -- PyTorch-ROCm ships its own ``libamdhip64.so.7``; loading it first
+makes our library bind to the same HIP runtime instance, so torch's device pointers and stream handles are
+valid inside our launches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvirnet_hip.so")
+ABI_VERSION = 1
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [("nrep", C.c_int), ("n_pad", C.c_int), ("cin_pad", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wpack", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+        ("mul", C.c_void_p), ("add", C.c_void_p), ("y_raw", C.c_void_p), ("y_act", C.c_void_p),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int),
+        ("n_pad", C.c_int), ("nrep", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("epi", C.c_int),
+        ("nchw_op", C.c_int), ("crop_h", C.c_int), ("crop_w", C.c_int), ("res_sf", C.c_int),
+        ("slope", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+    ]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("vec", C.c_void_p), ("map", C.c_void_p), ("out", C.c_void_p),
+        ("n", C.c_int), ("c0", C.c_int), ("h", C.c_int), ("w", C.c_int), ("sf", C.c_int),
+        ("ev", C.c_int),
+        ("em", C.c_int), ("mh", C.c_int), ("mw", C.c_int), ("msf", C.c_int), ("map_sqrt", C.c_int),
+        ("hp", C.c_int), ("wp", C.c_int),
+    ]
+
+
+class SftWeights(C.Structure):
+    _fields_ = [
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("wm", C.c_void_p), ("bm", C.c_void_p), ("wa", C.c_void_p), ("ba", C.c_void_p),
+        ("e", C.c_int), ("nf1", C.c_int), ("nf2", C.c_int), ("nf", C.c_int),
+    ]
+
+
+EPI_NHWC, EPI_CONVT, EPI_NCHW = 0, 1, 2
+GAP_MEAN, GAP_EXPCLAMP, GAP_KINFO = 0, 1, 2
+NCHW_PLAIN, NCHW_ADD, NCHW_EXPCLAMP = 0, 1, 2
+
+# every symbol include/virnet_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("virnet_abi_version", C.c_int, []),
+    ("virnet_last_error", C.c_char_p, []),
+    ("virnet_device_count", C.c_int, []),
+    ("virnet_packed_weight_floats", C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    ("virnet_pack_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    ("virnet_conv_get_plan", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvPlan)]),
+    ("virnet_conv_mfma", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    ("virnet_pack_input", C.c_int, [C.POINTER(PackDesc), C.c_void_p]),
+    ("virnet_conv_head_s4", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    ("virnet_gap_nchw", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  C.c_float, C.c_void_p]),
+    ("virnet_ca_gate", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_scale_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_sft_vec", C.c_int, [C.c_void_p, C.POINTER(SftWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("virnet_sft_apply", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SftWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]),
+]
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library; raise loudly when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the VIRNet HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C virnet_amd/csrc`) -- there is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.virnet_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"{LIB_PATH}: ABI {lib.virnet_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().virnet_last_error()
+        raise RuntimeError(f"libvirnet_hip {what}: {msg.decode() if msg else 'unknown error'}")
+
+
+def ptr(t) -> int:
+    """Device address of a tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    """hipStream_t of torch's current stream, as the void* the C ABI takes."""
+    return torch.cuda.current_stream().cuda_stream

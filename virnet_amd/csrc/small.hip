@@ -1,0 +1,299 @@
+// small.hip -- the latency-bound pieces around the MFMA convolutions: KNet's strided head, global average pools with their
+// finishing ops, the CALayer gate, and the SFT (AttLayer) generators.  None of these is a dense contraction worth MFMA tiles:
+// they are reductions / tiny per-image or per-pixel MLPs, written as plain wave64 VALU kernels with LDS reductions.
+#include "common.h"
+#include "../../include/virnet_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+// ----------------------------------------------------------------------------------------------------------------
+// KernelNet.head (networks/KNet.py:45,53): Conv2d(cin -> 64-multiple, k=9, s=4, p=4, no bias), NCHW in, NHWC out.
+// Block: 256 threads = 4 output pixels x 64 output channels; the [K][64] weight tile sits transposed in LDS (row stride 65
+// floats -> conflict-free for both the transposing write and the channel-parallel read).
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_head_s4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ out, int n, int cin, int h, int wd, int cout,
+                                                           int oh, int ow, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][65]
+  const int K = cin * 81;
+  const int ctile = blockIdx.y;  // 64 output channels
+  for (int i = threadIdx.x; i < K * 64; i += 256) {
+    const int co = i / K, k = i - co * K;
+    wl[k * 65 + co] = w[(size_t)(ctile * 64 + co) * K + k];
+  }
+  __syncthreads();
+  const int co = threadIdx.x & 63, ps = threadIdx.x >> 6;
+  const long npix = (long)n * oh * ow;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  for (long p = p0 + ps; p < p0 + pix_per_block && p < npix; p += 4) {
+    const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), img = (int)(p / ((long)ow * oh));
+    float acc = 0.f;
+    for (int ci = 0; ci < cin; ++ci) {
+      const float* xp = x + ((size_t)img * cin + ci) * h * wd;
+      for (int ky = 0; ky < 9; ++ky) {
+        const int iy = oy * 4 - 4 + ky;
+        if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 9; ++kx) {
+          const int ix = ox * 4 - 4 + kx;
+          if ((unsigned)ix < (unsigned)wd) acc = fmaf(xp[(size_t)iy * wd + ix], wl[((ci * 9 + ky) * 9 + kx) * 65 + co], acc);
+        }
+      }
+    }
+    out[(size_t)p * cout + ctile * 64 + co] = acc;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// block-wide sum of one float per thread (256 threads): wave64 shuffles, then 4 partials through LDS.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// planar GAP: one block per (n, c) plane
+__global__ __launch_bounds__(256) void gap_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int c, int hw,
+                                                       int finish, float lo, float hi) {
+  __shared__ float red[4];
+  const float* p = x + (size_t)blockIdx.x * hw;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < hw; i += 256) s += p[i];
+  const float mean = block_sum_256(s, red) / (float)hw;
+  if (threadIdx.x == 0) {
+    const int ch = blockIdx.x % c;
+    float v = mean;
+    if (finish == VIRNET_GAP_EXPCLAMP || (finish == VIRNET_GAP_KINFO && ch < c - 1)) v = expf(fminf(fmaxf(mean, lo), hi));
+    else if (finish == VIRNET_GAP_KINFO) v = tanhf(mean);
+    out[blockIdx.x] = v;
+  }
+}
+
+// CALayer gate: block per image. threads = (256/c pixel phases) x c channels
+__global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, float* __restrict__ gate, int hw, int c,
+                                                      int cr) {
+  __shared__ float part[256];
+  __shared__ float mean[256];
+  __shared__ float f1[64];
+  const int img = blockIdx.x;
+  const int ch = threadIdx.x % c, ph = threadIdx.x / c, nph = 256 / c;
+  const float* p = x + (size_t)img * hw * c;
+  float s = 0.f;
+  for (int i = ph; i < hw; i += nph) s += p[(size_t)i * c + ch];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < c) {
+    float t = 0.f;
+    for (int k = 0; k < nph; ++k) t += part[k * c + threadIdx.x];
+    mean[threadIdx.x] = t / (float)hw;
+  }
+  __syncthreads();
+  if (threadIdx.x < cr) {
+    float t = b1[threadIdx.x];
+    for (int k = 0; k < c; ++k) t = fmaf(w1[threadIdx.x * c + k], mean[k], t);
+    f1[threadIdx.x] = lrelu(t, 0.2f);
+  }
+  __syncthreads();
+  if (threadIdx.x < c) {
+    float t = b2[threadIdx.x];
+    for (int k = 0; k < cr; ++k) t = fmaf(w2[threadIdx.x * cr + k], f1[k], t);
+    gate[(size_t)img * c + threadIdx.x] = sigmoidf(t);
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(const float4* __restrict__ hcv, const float* __restrict__ gate,
+                                                        const float4* __restrict__ skip, float4* __restrict__ out, int hw,
+                                                        int c4, size_t total4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+    const int cq = (int)(i % c4);
+    const size_t img = i / ((size_t)hw * c4);
+    const float4 g = reinterpret_cast<const float4*>(gate + img * c4 * 4)[cq];
+    const float4 a = hcv[i], b = skip[i];
+    out[i] = make_float4(fmaf(a.x, g.x, b.x), fmaf(a.y, g.y, b.y), fmaf(a.z, g.z, b.z), fmaf(a.w, g.w, b.w));
+  }
+}
+
+// AttLayer on a per-image vector: block per image
+__global__ __launch_bounds__(256) void sft_vec_kernel(const float* __restrict__ vec, const virnet_sft_weights wt,
+                                                      float* __restrict__ mul, float* __restrict__ add) {
+  __shared__ float e[16];
+  __shared__ float f1[64];
+  __shared__ float f2[128];
+  const int img = blockIdx.x;
+  if (threadIdx.x < wt.e) e[threadIdx.x] = vec[(size_t)img * wt.e + threadIdx.x];
+  __syncthreads();
+  for (int j = threadIdx.x; j < wt.nf1; j += 256) {
+    float t = wt.b1[j];
+    for (int k = 0; k < wt.e; ++k) t = fmaf(wt.w1[j * wt.e + k], e[k], t);
+    f1[j] = lrelu(t, 0.2f);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < wt.nf2; j += 256) {
+    float t = wt.b2[j];
+    for (int k = 0; k < wt.nf1; ++k) t = fmaf(wt.w2[j * wt.nf1 + k], f1[k], t);
+    f2[j] = lrelu(t, 0.2f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < wt.nf; c += 256) {
+    float tm = wt.bm[c], ta = wt.ba[c];
+    for (int k = 0; k < wt.nf2; ++k) {
+      tm = fmaf(wt.wm[c * wt.nf2 + k], f2[k], tm);
+      ta = fmaf(wt.wa[c * wt.nf2 + k], f2[k], ta);
+    }
+    mul[(size_t)img * wt.nf + c] = sigmoidf(tm);
+    add[(size_t)img * wt.nf + c] = ta;
+  }
+}
+
+// AttLayer per pixel + SFT + LeakyReLU: block = PT pixels; thread <-> output channel (looped), weights read once per block
+constexpr int SFT_PT = 16;
+__global__ __launch_bounds__(256) void sft_apply_kernel(const float* __restrict__ raw, const float* __restrict__ rec,
+                                                        const virnet_sft_weights wt, float* __restrict__ act, int n, int h, int w,
+                                                        int step, int chan0) {
+  __shared__ float e[SFT_PT][16];
+  __shared__ float f1[SFT_PT][64];
+  __shared__ float f2[SFT_PT][128];
+  const size_t npix = (size_t)n * h * w;
+  const size_t p0 = (size_t)blockIdx.x * SFT_PT;
+  const int hp = h * step, wp = w * step;
+  for (int i = threadIdx.x; i < SFT_PT * wt.e; i += 256) {
+    const int pi = i / wt.e, k = i - pi * wt.e;
+    const size_t p = p0 + pi;
+    float v = 0.f;
+    if (p < npix) {
+      const int x = (int)(p % w), y = (int)((p / w) % h), img = (int)(p / ((size_t)w * h));
+      v = rec[(((size_t)img * hp + (size_t)y * step) * wp + (size_t)x * step) * 16 + chan0 + k];
+    }
+    e[pi][k] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SFT_PT * wt.nf1; i += 256) {
+    const int pi = i / wt.nf1, j = i - pi * wt.nf1;
+    float t = wt.b1[j];
+    for (int k = 0; k < wt.e; ++k) t = fmaf(wt.w1[j * wt.e + k], e[pi][k], t);
+    f1[pi][j] = lrelu(t, 0.2f);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < SFT_PT * wt.nf2; i += 256) {
+    const int pi = i / wt.nf2, j = i - pi * wt.nf2;
+    float t = wt.b2[j];
+    for (int k = 0; k < wt.nf1; ++k) t = fmaf(wt.w2[j * wt.nf1 + k], f1[pi][k], t);
+    f2[pi][j] = lrelu(t, 0.2f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < wt.nf; c += 256) {
+    float tm[SFT_PT], ta[SFT_PT];
+#pragma unroll
+    for (int pi = 0; pi < SFT_PT; ++pi) { tm[pi] = wt.bm[c]; ta[pi] = wt.ba[c]; }
+    for (int k = 0; k < wt.nf2; ++k) {
+      const float wm = wt.wm[c * wt.nf2 + k], wa = wt.wa[c * wt.nf2 + k];
+#pragma unroll
+      for (int pi = 0; pi < SFT_PT; ++pi) {
+        tm[pi] = fmaf(wm, f2[pi][k], tm[pi]);
+        ta[pi] = fmaf(wa, f2[pi][k], ta[pi]);
+      }
+    }
+#pragma unroll
+    for (int pi = 0; pi < SFT_PT; ++pi) {
+      const size_t p = p0 + pi;
+      if (p < npix) {
+        const size_t o = p * wt.nf + c;
+        act[o] = lrelu(fmaf(raw[o], sigmoidf(tm[pi]), ta[pi]), 0.2f);
+      }
+    }
+  }
+}
+
+int check_sft(const virnet_sft_weights* wt, const char* who) {
+  VIRNET_REQUIRE(wt && wt->w1 && wt->b1 && wt->w2 && wt->b2 && wt->wm && wt->bm && wt->wa && wt->ba, "%s: NULL weights", who);
+  VIRNET_REQUIRE(wt->e >= 1 && wt->e <= 16 && wt->nf1 >= 1 && wt->nf1 <= 64 && wt->nf2 >= 1 && wt->nf2 <= 128 && wt->nf >= 1,
+                 "%s: unsupported widths e=%d nf1=%d nf2=%d nf=%d", who, wt->e, wt->nf1, wt->nf2, wt->nf);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int virnet_conv_head_s4(const float* x, const float* w, float* out, int n, int cin, int h, int w_, int cout,
+                                   void* stream) {
+  VIRNET_REQUIRE(x && w && out, "virnet_conv_head_s4: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && h > 0 && w_ > 0 && cin > 0, "virnet_conv_head_s4: bad shape");
+  VIRNET_REQUIRE(cout % 64 == 0 && cout > 0, "virnet_conv_head_s4: cout=%d must be a multiple of 64", cout);
+  const int K = cin * 81;
+  const size_t lds = (size_t)K * 65 * sizeof(float);
+  VIRNET_REQUIRE(lds <= 160 * 1024, "virnet_conv_head_s4: cin=%d too large for the LDS weight tile", cin);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_s4_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_head_s4): %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  const int oh = (h - 1) / 4 + 1, ow = (w_ - 1) / 4 + 1;
+  const long npix = (long)n * oh * ow;
+  int ppb = 32;
+  while ((npix + ppb - 1) / ppb > 2048) ppb *= 2;
+  const int gx = (int)((npix + ppb - 1) / ppb);
+  hipLaunchKernelGGL(conv_head_s4_kernel, dim3(gx, cout / 64), dim3(256), lds, static_cast<hipStream_t>(stream), x, w, out, n,
+                     cin, h, w_, cout, oh, ow, ppb);
+  return virnet::check_launch("conv_head_s4 launch");
+}
+
+extern "C" int virnet_gap_nchw(const float* x, float* out, int n, int c, int h, int w, int finish, float lo, float hi,
+                               void* stream) {
+  VIRNET_REQUIRE(x && out, "virnet_gap_nchw: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "virnet_gap_nchw: bad shape");
+  VIRNET_REQUIRE(finish >= VIRNET_GAP_MEAN && finish <= VIRNET_GAP_KINFO, "virnet_gap_nchw: finish=%d", finish);
+  hipLaunchKernelGGL(gap_nchw_kernel, dim3(n * c), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, c, h * w, finish, lo,
+                     hi);
+  return virnet::check_launch("gap_nchw launch");
+}
+
+extern "C" int virnet_ca_gate(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* gate,
+                              int n, int h, int w, int c, int cr, void* stream) {
+  VIRNET_REQUIRE(x && w1 && b1 && w2 && b2 && gate, "virnet_ca_gate: NULL pointer");
+  VIRNET_REQUIRE(c >= 1 && c <= 256 && 256 % c == 0, "virnet_ca_gate: c=%d must divide 256", c);
+  VIRNET_REQUIRE(cr >= 1 && cr <= 64, "virnet_ca_gate: cr=%d", cr);
+  hipLaunchKernelGGL(ca_gate_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), x, w1, b1, w2, b2, gate, h * w, c,
+                     cr);
+  return virnet::check_launch("ca_gate launch");
+}
+
+extern "C" int virnet_scale_add(const float* hcv, const float* gate, const float* skip, float* out, int n, int hw, int c,
+                                void* stream) {
+  VIRNET_REQUIRE(hcv && gate && skip && out, "virnet_scale_add: NULL pointer");
+  VIRNET_REQUIRE(c % 4 == 0 && c > 0, "virnet_scale_add: c=%d must be a multiple of 4", c);
+  const size_t total4 = (size_t)n * hw * (c / 4);
+  const int grid = (int)((total4 + 255) / 256 > 8192 ? 8192 : (total4 + 255) / 256);
+  hipLaunchKernelGGL(scale_add_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(hcv), gate, reinterpret_cast<const float4*>(skip),
+                     reinterpret_cast<float4*>(out), hw, c / 4, total4);
+  return virnet::check_launch("scale_add launch");
+}
+
+extern "C" int virnet_sft_vec(const float* vec, const virnet_sft_weights* wt, float* mul, float* add, int n, void* stream) {
+  VIRNET_REQUIRE(vec && mul && add && n > 0, "virnet_sft_vec: bad arguments");
+  if (int rc = check_sft(wt, "virnet_sft_vec")) return rc;
+  hipLaunchKernelGGL(sft_vec_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), vec, *wt, mul, add);
+  return virnet::check_launch("sft_vec launch");
+}
+
+extern "C" int virnet_sft_apply(const float* raw, const float* rec, const virnet_sft_weights* wt, float* act, int n, int h,
+                                int w, int step, int chan0, void* stream) {
+  VIRNET_REQUIRE(raw && rec && act && n > 0 && h > 0 && w > 0 && step >= 1, "virnet_sft_apply: bad arguments");
+  if (int rc = check_sft(wt, "virnet_sft_apply")) return rc;
+  VIRNET_REQUIRE(chan0 >= 0 && chan0 + wt->e <= 16, "virnet_sft_apply: channels [%d,%d) outside the 16-channel record", chan0,
+                 chan0 + wt->e);
+  const size_t npix = (size_t)n * h * w;
+  hipLaunchKernelGGL(sft_apply_kernel, dim3((unsigned)((npix + SFT_PT - 1) / SFT_PT)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), raw, rec, *wt, act, n, h, w, step, chan0);
+  return virnet::check_launch("sft_apply launch");
+}

@@ -1,0 +1,54 @@
+"""Parameter holders.
+
+The reference keeps its weights in ``nn.Conv2d`` / ``nn.ConvTranspose2d`` leaves; here a leaf only OWNS the
+parameters (same names, shapes, dtype, default initialisation, so ``state_dict`` round-trips with the
+reference's checkpoints) and caches their MFMA-stage packing.  The arithmetic runs in ``libvirnet_hip``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class ConvParam(nn.Module):
+    """``weight`` (+ ``bias``) of an nn.Conv2d (OIHW) or, with ``transposed``, an nn.ConvTranspose2d (IOHW)."""
+
+    def __init__(self, cin: int, cout: int, ks: int, bias: bool = True, transposed: bool = False, stride: int = 1):
+        super().__init__()
+        self.cin, self.cout, self.ks, self.transposed, self.stride = cin, cout, ks, transposed, stride
+        shape = (cin, cout, ks, ks) if transposed else (cout, cin, ks, ks)
+        self.weight = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.reset_parameters()
+        self._pack: Optional[ops.PackedWeight] = None
+        self._pack_key = None
+
+    def reset_parameters(self) -> None:
+        # torch's default for _ConvNd.reset_parameters (what the reference's un-initialised convs get)
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def packed(self) -> ops.PackedWeight:
+        """Packed weight for the MFMA kernel, rebuilt when the parameter storage or version changed."""
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        if self._pack is None or self._pack_key != key:
+            self._pack = ops.pack_weight(self.weight, self.bias, transposed=self.transposed, stride=self.stride)
+            self._pack_key = key
+        return self._pack
+
+    def forward(self, *args, **kwargs):  # pragma: no cover - guard
+        raise RuntimeError("ConvParam holds parameters only; the convolution runs inside libvirnet_hip "
+                           "(call the enclosing network's forward)")
+
+    def extra_repr(self) -> str:
+        kind = "convT" if self.transposed else "conv"
+        return f"{kind} {self.cin}->{self.cout}, k={self.ks}, s={self.stride}, bias={self.bias is not None}"

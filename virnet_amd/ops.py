@@ -1,0 +1,234 @@
+"""Tensor-level wrappers over the C ABI: torch supplies device memory and the stream, nothing else.
+
+Activations between kernels are NHWC fp32 tensors ``[N, H, W, C]`` (C a multiple of 16); images and the
+returned maps are NCHW like the reference's.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as nat
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class PackedWeight:
+    """MFMA-stage image of one conv / transposed-conv weight plus the plan it was packed for."""
+    w: Tensor            # flat fp32 device tensor
+    bias: Optional[Tensor]
+    ks: int              # GEMM taps per side (1 for the transposed conv)
+    cout: int
+    cin_pad: int
+    n_pad: int
+    nrep: int
+    transposed: bool
+
+
+def _dev_check(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the VIRNet HIP path needs tensors on a ROCm device "
+                           f"(no CPU fallback exists; move the module and inputs with .cuda())")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+
+
+def get_plan(ks: int, stride: int, cin: int, gemm_n: int) -> nat.ConvPlan:
+    plan = nat.ConvPlan()
+    nat.check(nat.load().virnet_conv_get_plan(ks, stride, cin, gemm_n, C.byref(plan)), "conv_get_plan")
+    return plan
+
+
+def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = False, stride: int = 1) -> PackedWeight:
+    """Pack an OIHW conv weight or an IOHW (k=2,s=2) transposed-conv weight for virnet_conv_mfma."""
+    lib = nat.load()
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    if transposed:
+        cin, cout, kh, kw = weight.shape
+        if (kh, kw) != (2, 2):
+            raise ValueError("only ConvTranspose2d(k=2, s=2) is on the path (networks/AttResUNet.py:80)")
+        plan = get_plan(1, 1, cin, 4 * cout)
+        gemm_ks, kind, ks = 1, 1, 2
+    else:
+        cout, cin, kh, kw = weight.shape
+        if kh != kw or kh not in (1, 3):
+            raise ValueError(f"unsupported kernel {kh}x{kw}")
+        plan = get_plan(kh, stride, cin, cout)
+        gemm_ks, kind, ks = kh, 0, kh
+    n = lib.virnet_packed_weight_floats(gemm_ks, plan.cin_pad, plan.n_pad)
+    out = torch.empty(n, dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_weight(nat.ptr(weight), kind, cout, cin, ks, plan.cin_pad, plan.n_pad, plan.nrep,
+                                     nat.ptr(out), nat.stream_handle()), "pack_weight")
+    b = None
+    if bias is not None:
+        b = bias.detach()
+        _dev_check(b, "bias")
+    return PackedWeight(out, b, gemm_ks, cout, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
+
+
+def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
+              mul: Optional[Tensor] = None, add: Optional[Tensor] = None, want_raw: bool = True,
+              want_act: bool = False, slope: float = 0.2) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """NHWC conv (or transposed conv when ``pw.transposed``) -> (raw, act), each NHWC or None."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    if c != pw.cin_pad:
+        raise ValueError(f"x has {c} channels, packed weight expects {pw.cin_pad}")
+    if pw.transposed:
+        oh, ow, epi = 2 * h, 2 * w, nat.EPI_CONVT
+    else:
+        oh, ow, epi = h // stride, w // stride, nat.EPI_NHWC
+    raw = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_raw else None
+    act = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_act else None
+    for t, nm in ((res, "res"), (mul, "mul"), (add, "add")):
+        if t is not None:
+            _dev_check(t, nm)
+    if res is not None and tuple(res.shape) != (n, oh, ow, pw.cout):
+        raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, pw.cout)}")
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
+                     add=nat.ptr(add), y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c,
+                     cout=pw.cout, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks, stride=stride, epi=epi, nchw_op=0,
+                     crop_h=0, crop_w=0, res_sf=1, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
+    nat.check(nat.load().virnet_conv_mfma(C.byref(d), nat.stream_handle()), "conv_mfma")
+    return raw, act
+
+
+def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: int = nat.NCHW_PLAIN,
+                   res: Optional[Tensor] = None, res_sf: int = 1, clamp: Tuple[float, float] = (0.0, 0.0)) -> Tensor:
+    """Thin-output 3x3 conv with planar (NCHW) store, crop and fused `+res` / `exp(clamp(.))` epilogue.
+
+    With ``res_sf`` > 1 ``res`` is the low-resolution image and is added through a nearest up-sampling."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    if c != pw.cin_pad:
+        raise ValueError(f"x has {c} channels, packed weight expects {pw.cin_pad}")
+    ch, cw = crop_hw
+    out = torch.empty((n, pw.cout, ch, cw), dtype=torch.float32, device=x.device)
+    if res is not None:
+        _dev_check(res, "res")
+        if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
+            raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0,
+                     y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
+                     nrep=pw.nrep, ks=pw.ks, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
+                     res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
+    nat.check(nat.load().virnet_conv_mfma(C.byref(d), nat.stream_handle()), "conv_mfma(nchw)")
+    return out
+
+
+def pack_input(x: Tensor, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor] = None,
+               map_: Optional[Tensor] = None, map_sf: int = 1, map_sqrt: bool = False) -> Tensor:
+    """NCHW image (+ per-image vector / per-pixel map) -> [N, hp, wp, 16] NHWC records (up-sample, reflect pad, concat)."""
+    _dev_check(x, "x")
+    n, c0, h, w = x.shape
+    ev = 0 if vec is None else vec.shape[1]
+    em, mh, mw = (0, 0, 0) if map_ is None else map_.shape[1:]
+    if vec is not None:
+        _dev_check(vec, "vec")
+    if map_ is not None:
+        _dev_check(map_, "map")
+    out = torch.empty((n, hp, wp, 16), dtype=torch.float32, device=x.device)
+    d = nat.PackDesc(x=nat.ptr(x), vec=nat.ptr(vec), map=nat.ptr(map_), out=nat.ptr(out), n=n, c0=c0, h=h, w=w, sf=sf,
+                     ev=ev, em=em, mh=mh, mw=mw, msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp)
+    nat.check(nat.load().virnet_pack_input(C.byref(d), nat.stream_handle()), "pack_input")
+    return out
+
+
+GAP_MEAN, GAP_EXPCLAMP, GAP_KINFO = nat.GAP_MEAN, nat.GAP_EXPCLAMP, nat.GAP_KINFO
+
+
+def gap_nchw(x: Tensor, finish: int = GAP_MEAN, clamp: Tuple[float, float] = (0.0, 0.0)) -> Tensor:
+    """Planar global average pool [N,C,H,W] -> [N,C] with the call site's finishing op fused."""
+    _dev_check(x, "x")
+    n, c, h, w = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    nat.check(nat.load().virnet_gap_nchw(nat.ptr(x), nat.ptr(out), n, c, h, w, finish, clamp[0], clamp[1],
+                                         nat.stream_handle()), "gap_nchw")
+    return out
+
+
+def conv_head_s4(x: Tensor, weight: Tensor) -> Tensor:
+    """KernelNet.head: 9x9 stride-4 pad-4 conv without bias, NCHW in -> NHWC out."""
+    _dev_check(x, "x")
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    if tuple(weight.shape[1:]) != (cin, 9, 9):
+        raise ValueError(f"head weight {tuple(weight.shape)} does not match a 9x9 conv on {cin} channels")
+    oh, ow = (h - 1) // 4 + 1, (w - 1) // 4 + 1
+    out = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    nat.check(nat.load().virnet_conv_head_s4(nat.ptr(x), nat.ptr(weight), nat.ptr(out), n, cin, h, w, cout,
+                                             nat.stream_handle()), "conv_head_s4")
+    return out
+
+
+def ca_gate(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """CALayer gate [N,C] from NHWC features."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    cr = w1.shape[0]
+    ts = [t.detach() for t in (w1, b1, w2, b2)]
+    for t in ts:
+        _dev_check(t, "CALayer parameter")
+    gate = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    nat.check(nat.load().virnet_ca_gate(nat.ptr(x), *(nat.ptr(t) for t in ts), nat.ptr(gate), n, h, w, c, cr,
+                                        nat.stream_handle()), "ca_gate")
+    return gate
+
+
+def scale_add(hcv: Tensor, gate: Tensor, skip: Tensor) -> Tensor:
+    """hcv * gate[n,c] + skip on NHWC tensors."""
+    _dev_check(hcv, "hcv"); _dev_check(skip, "skip"); _dev_check(gate, "gate")
+    n, h, w, c = hcv.shape
+    out = torch.empty_like(hcv)
+    nat.check(nat.load().virnet_scale_add(nat.ptr(hcv), nat.ptr(gate), nat.ptr(skip), nat.ptr(out), n, h * w, c,
+                                          nat.stream_handle()), "scale_add")
+    return out
+
+
+def _sft_weights(att) -> Tuple[nat.SftWeights, list]:
+    ps = [att.conv1.weight, att.conv1.bias, att.conv2.weight, att.conv2.bias, att.mul_conv.weight, att.mul_conv.bias,
+          att.add_conv.weight, att.add_conv.bias]
+    ts = [p.detach() for p in ps]
+    for t in ts:
+        _dev_check(t, "AttLayer parameter")
+    wt = nat.SftWeights(*(nat.ptr(t) for t in ts), e=att.conv1.cin, nf1=att.conv1.cout, nf2=att.conv2.cout,
+                        nf=att.mul_conv.cout)
+    return wt, ts
+
+
+def sft_vec(vec: Tensor, att) -> Tuple[Tensor, Tensor]:
+    """AttLayer on spatially constant conditioning: (mul, add), each [N, nf]."""
+    _dev_check(vec, "vec")
+    n = vec.shape[0]
+    wt, keep = _sft_weights(att)
+    if vec.shape[1] != wt.e:
+        raise ValueError(f"conditioning vector has {vec.shape[1]} channels, AttLayer expects {wt.e}")
+    mul = torch.empty((n, wt.nf), dtype=torch.float32, device=vec.device)
+    add = torch.empty_like(mul)
+    nat.check(nat.load().virnet_sft_vec(nat.ptr(vec), C.byref(wt), nat.ptr(mul), nat.ptr(add), n, nat.stream_handle()),
+              "sft_vec")
+    return mul, add
+
+
+def sft_apply(raw: Tensor, rec: Tensor, chan0: int, nchan: int, step: int, att) -> Tensor:
+    """lrelu(raw * mul(e) + add(e)) with the AttLayer evaluated per pixel on channels [chan0, chan0+nchan) of ``rec``."""
+    _dev_check(raw, "raw"); _dev_check(rec, "rec")
+    n, h, w, nf = raw.shape
+    wt, keep = _sft_weights(att)
+    if nchan != wt.e or nf != wt.nf:
+        raise ValueError(f"AttLayer({wt.e}->{wt.nf}) does not match conditioning {nchan} / features {nf}")
+    if tuple(rec.shape) != (n, h * step, w * step, 16):
+        raise ValueError(f"rec shape {tuple(rec.shape)} != {(n, h * step, w * step, 16)}")
+    act = torch.empty_like(raw)
+    nat.check(nat.load().virnet_sft_apply(nat.ptr(raw), nat.ptr(rec), C.byref(wt), nat.ptr(act), n, h, w, step, chan0,
+                                          nat.stream_handle()), "sft_apply")
+    return act
