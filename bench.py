@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Benchmark of the VIRNet denoise forward (VIRAttResUNet, denoise-syn config) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one forward of the hot path over one resident batch of synthetic images.  Default workload = the configuration
+BASELINE.json's metric is quoted on -- 256x256x3 images, 32 per GPU (configs[2]'s per-GPU shard; at N=8 the global batch is
+configs[2]'s 256).  ``--size 128 --batch 64`` runs configs[1].  Scaling is weak: every rank owns ``--batch`` images, the only
+collective is the start-up weight broadcast (RCCL), nothing is exchanged per image.
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  roofline     : the dominant kernel conv_mfma_kernel<3,1,2,3> (3x3 C->C res-block convs) -- algorithmic FLOPs per launch / its
+                 average launch duration, measured with HIP events recorded on the launch stream around every launch inside the
+                 timed region (rank 0), against the 157.3 TFLOP/s fp32-MFMA peak
+  cpu_baseline : the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from virnet_amd import dist as vdist  # noqa: E402
+from virnet_amd import ops  # noqa: E402
+from virnet_amd.networks import VIRAttResUNet  # noqa: E402
+from virnet_amd.utils.synth import synth_images, synth_state_dict  # noqa: E402
+
+# scripts/denoising_virnet_syn.py:62-71
+SYN_CFG = dict(n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input", noise_avg=False)
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+KFLOP_PER_PIXEL = 4988.736             # conv FLOPs (2*MAC) of the denoise-syn forward per padded pixel
+DOMINANT = (3, 1, 2, 3)                # conv_mfma_kernel<KS=3,STRIDE=1,MREP=2,NREP=3>
+
+
+def build_net(device):
+    net = VIRAttResUNet(im_chn=3, sigma_chn=1, **SYN_CFG)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    return net, sd
+
+
+def cpu_baseline(sd, size: int, budget_s: float = 20.0):
+    """Time the CPU oracle on all host cores on a bounded sample of the same workload."""
+    from oracle import cpu_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nimg = 2 if size >= 256 else 8
+    x = synth_images(nimg, 3, size, size)
+    with torch.no_grad():
+        cpu_ref.virnet_denoise(sd, x, **SYN_CFG)            # warm-up (thread pool, oneDNN primitive cache)
+        times = []
+        t_begin = time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_begin < budget_s or not times):
+            t0 = time.perf_counter()
+            cpu_ref.virnet_denoise(sd, x, **SYN_CFG)
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(nimg / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/cpu_ref.virnet_denoise on [{nimg},3,{size},{size}] fp32, torch CPU ({cores} threads), "
+                      f"median of {len(times)} runs after 1 warm-up"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/), else None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256, help="image height=width")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 @256, 64 @128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    batch = args.batch if args.batch is not None else (32 if args.size >= 256 else 64)
+
+    rank, local_rank, world = vdist.init()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    net, sd = build_net(dev)
+    if rank == 0:
+        net.load_state_dict(sd, strict=True)       # other ranks keep their random init until the broadcast
+    net = net.to(dev).eval()
+    t0 = time.perf_counter()
+    bcast_bytes = vdist.broadcast_parameters(net, src=0)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    # this rank's shard of the global batch (weak scaling: `batch` images per rank), resident in HBM before timing
+    a, b = vdist.shard_range(batch * world, world, rank)
+    x = synth_images(b - a, 3, args.size, args.size, seed=20240916 + rank).to(dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
+        torch.cuda.synchronize()
+        barrier()
+        ops.set_launch_timer(timer)     # two event records per conv launch, on the launch stream (~us of host time each)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mu, sigma = net(x)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.set_launch_timer(None)
+    elapsed = vdist.max_over_ranks(elapsed, dev)
+    assert torch.isfinite(mu).all()
+
+    roof = None
+    if timer is not None:
+        summ = timer.summary()
+        d = summ.get(DOMINANT)
+        if d:
+            avg_ms = d["ms"] / d["launches"]
+            achieved = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            total_ms = sum(v["ms"] for v in summ.values())
+            pmc = load_pmc_traffic()
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
+                    "kernel": "conv_mfma_kernel<3,1,2,3>", "launches_per_step": d["launches"] // args.steps,
+                    "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                    "flop_unit": "GFLOP (2*MAC, algorithmic)", "share_of_conv_time": round(d["ms"] / total_ms, 4),
+                    "by_kernel_ms_per_step": {"conv_mfma<%d,%d,%d,%d>" % k: round(v["ms"] / args.steps, 3)
+                                              for k, v in sorted(summ.items())}}
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        imgs = batch * world * args.steps
+        value = imgs / elapsed
+        hp = (args.size + 3) // 4 * 4
+        gflop_img = KFLOP_PER_PIXEL * hp * hp / 1e6
+        out = {
+            "metric": "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"VIRAttResUNet denoise-syn forward (n_feat 96/192/288, 3 res-blocks, dep_S 5), {args.size}x{args.size}x3 "
+                                   f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
+                       "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
+                       "parallelism": f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), no per-image collective"},
+            "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
+                          "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "roofline": roof,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd, args.size),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,9 @@ typedef struct virnet_conv_desc {
 } virnet_conv_desc;
 
 int virnet_conv_mfma(const virnet_conv_desc* d, void* stream);
+/* Which instantiation virnet_conv_mfma would launch for `d`: out = {KS, STRIDE, MREP, NREP} of
+ * conv_mfma_kernel<KS,STRIDE,MREP,NREP> (the name rocprofv3 reports).  Used by bench.py to attribute event timings. */
+int virnet_conv_mfma_variant(const virnet_conv_desc* d, int out[4]);
 
 /* ------------------------------------------------------------------------------------------------
  * Image entry: NCHW -> 16-channel NHWC pixel records, fusing

@@ -144,14 +144,14 @@ def test_pack_input_reflect_upsample_concat():
     ref = cpu_ref.pad_to_multiple(torch.cat([x, sig.sqrt()], 1), 4)
     out = ops.pack_input(x.cuda(), 40, 48, map_=sig.cuda(), map_sqrt=True)
     assert tuple(out.shape) == (2, 40, 48, 16)
-    assert maxerr(nchw(out)[:, :4], ref) <= 1e-7 and float(out[..., 4:].abs().max()) == 0.0
+    assert maxerr(nchw(out)[:, :4], ref) <= 2.4e-7 and float(out[..., 4:].abs().max()) == 0.0
     # SISR: nearest x3, per-image vector repeated, LR sigma map up-sampled x3, pad 27x33 -> 28x36
     xl, vec, sl = rnd(1, 3, 9, 11, seed=18), rnd(1, 3, seed=19), rnd(1, 1, 9, 11, seed=20, lo=0.1, hi=1)
     xu = F.interpolate(xl, scale_factor=3, mode="nearest")
     ex = torch.cat([xu, vec.view(1, 3, 1, 1).repeat(1, 1, 27, 33), F.interpolate(sl.sqrt(), scale_factor=3, mode="nearest")], 1)
     ref2 = cpu_ref.pad_to_multiple(ex, 4)
     out2 = ops.pack_input(xl.cuda(), 28, 36, sf=3, vec=vec.cuda(), map_=sl.cuda(), map_sf=3, map_sqrt=True)
-    assert maxerr(nchw(out2)[:, :7], ref2) <= 1e-7
+    assert maxerr(nchw(out2)[:, :7], ref2) <= 2.4e-7   # sqrtf may differ by 1 ulp
     with pytest.raises(RuntimeError, match="pad < dim"):   # F.pad reflect contract (util_net.py:24)
         ops.pack_input(rnd(1, 3, 2, 2).cuda(), 4, 4)
 

@@ -66,6 +66,7 @@ SYMBOLS = [
                                      C.c_void_p, C.c_void_p]),
     ("virnet_conv_get_plan", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(ConvPlan)]),
     ("virnet_conv_mfma", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    ("virnet_conv_mfma_variant", C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int * 4)]),
     ("virnet_pack_input", C.c_int, [C.POINTER(PackDesc), C.c_void_p]),
     ("virnet_conv_head_s4", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),

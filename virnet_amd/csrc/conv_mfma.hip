@@ -338,7 +338,21 @@ int pick_nrep(int nblocks32) {
   return 1;
 }
 
+// Small grids (deep U-Net levels, single images) use 4-row tiles so the 256 CUs still see >= 2 workgroups each.
+int pick_mrep(const virnet_conv_desc* d) {
+  if (d->stride == 2 || d->nrep == 7) return 1;
+  const int oh = d->h, ow = d->w;
+  const long wg8 = (long)d->n * ((oh + 7) / 8) * ((ow + 31) / 32) * (d->n_pad / (32 * d->nrep));
+  return wg8 < 2048 ? 1 : 2;
+}
+
 }  // namespace
+
+extern "C" int virnet_conv_mfma_variant(const virnet_conv_desc* d, int out[4]) {
+  VIRNET_REQUIRE(d && out, "virnet_conv_mfma_variant: NULL pointer");
+  out[0] = d->ks; out[1] = d->stride; out[2] = pick_mrep(d); out[3] = d->nrep;
+  return 0;
+}
 
 extern "C" int virnet_conv_get_plan(int ks, int stride, int cin, int gemm_n, virnet_conv_plan* plan) {
   VIRNET_REQUIRE(plan != nullptr, "virnet_conv_get_plan: plan is NULL");
@@ -396,9 +410,7 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
       return virnet::set_error("virnet_conv_mfma: unknown epilogue %d", d->epi);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // Small grids (deep U-Net levels, single images) use 4-row tiles so the 256 CUs still see >= 2 workgroups each.
-  const long wg8 = (long)d->n * ((k.OH + 7) / 8) * ((k.OW + 31) / 32) * (d->n_pad / (32 * d->nrep));
-  const bool small = wg8 < 2048;
+  const bool small = pick_mrep(d) == 1;
 #define VIRNET_CASE(KS_, S_, M_, N_) return launch<KS_, S_, M_, N_>(k, st)
   if (d->ks == 3 && d->stride == 1) {
     switch (d->nrep) {

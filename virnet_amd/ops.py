@@ -23,10 +23,52 @@ class PackedWeight:
     bias: Optional[Tensor]
     ks: int              # GEMM taps per side (1 for the transposed conv)
     cout: int
+    cin_real: int
     cin_pad: int
     n_pad: int
     nrep: int
     transposed: bool
+
+
+class LaunchTimer:
+    """Optional per-launch HIP-event timing of the MFMA convolutions (used by bench.py for the roofline line).
+
+    Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []   # (variant tuple, algorithmic flops, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for var, flops, e0, e1 in self.records:
+            d = out.setdefault(var, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+        return out
+
+
+_TIMER: Optional[LaunchTimer] = None
+
+
+def set_launch_timer(t: Optional[LaunchTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def _launch_conv(d: "nat.ConvDesc", flops: float, what: str) -> None:
+    lib = nat.load()
+    if _TIMER is None:
+        nat.check(lib.virnet_conv_mfma(C.byref(d), nat.stream_handle()), what)
+        return
+    var = (C.c_int * 4)()
+    nat.check(lib.virnet_conv_mfma_variant(C.byref(d), C.byref(var)), what)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    nat.check(lib.virnet_conv_mfma(C.byref(d), nat.stream_handle()), what)
+    e1.record()
+    _TIMER.records.append((tuple(var), flops, e0, e1))
 
 
 def _dev_check(t: Tensor, name: str) -> None:
@@ -70,7 +112,7 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
     if bias is not None:
         b = bias.detach()
         _dev_check(b, "bias")
-    return PackedWeight(out, b, gemm_ks, cout, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
+    return PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
 
 
 def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
@@ -96,7 +138,9 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
                      add=nat.ptr(add), y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c,
                      cout=pw.cout, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks, stride=stride, epi=epi, nchw_op=0,
                      crop_h=0, crop_w=0, res_sf=1, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
-    nat.check(nat.load().virnet_conv_mfma(C.byref(d), nat.stream_handle()), "conv_mfma")
+    # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
+    flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
+    _launch_conv(d, flops, "conv_mfma")
     return raw, act
 
 
@@ -119,7 +163,7 @@ def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op:
                      y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
                      nrep=pw.nrep, ks=pw.ks, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
                      res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
-    nat.check(nat.load().virnet_conv_mfma(C.byref(d), nat.stream_handle()), "conv_mfma(nchw)")
+    _launch_conv(d, 2.0 * n * h * w * pw.cin_real * pw.cout * pw.ks ** 2, "conv_mfma(nchw)")
     return out
 
 
