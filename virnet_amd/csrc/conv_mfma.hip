@@ -6,29 +6,33 @@
 //   KS=3,S=2  DownBlock.downsampler (networks/AttResUNet.py:67)
 //   KS=1,S=1  UpBlock.upsampler, ConvTranspose2d(k2,s2) == 1x1 GEMM to 4*Cout columns + depth-to-space (AttResUNet.py:80)
 //
-// GEMM view: M = output pixels, N = output channels, K = KS*KS*Cin.  v_mfma_f32_32x32x2_f32 is exact fp32 (an fmaf chain),
-// so parity with the reference's fp32 conv is at re-association level (~1e-6), far inside the 1e-3 contract.
+// GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (tap, cin).  v_mfma_f32_32x32x2_f32 is exact fp32 (an fmaf
+// chain), so parity with the reference's fp32 conv is at re-association level (~1e-6), far inside the 1e-3 contract.
 //
-// Workgroup = 4 waves = (4*MREP) output rows x 32 output columns x NB=32*NREP output channels.
-// Wave w owns rows [w*MREP, (w+1)*MREP); an MFMA "M" block is 32 consecutive pixels of one row.
-// K is walked as 16-channel chunks x KS*KS taps ("stages"); per stage a wave issues MREP*NREP*8 MFMAs.
+// Workgroup = 4 waves = (4*MREP) output rows x 32 output columns x NB=32*NREP output channels; wave w owns rows
+// [w*MREP, (w+1)*MREP); one MFMA column block is 32 consecutive pixels of a row.  K is walked as 16-channel chunks x KS*KS
+// taps x 2 half-steps of 8 channels; per half-step a wave issues MREP*NREP*4 MFMAs.
 //
-// LDS (all dynamic, 16-B aligned):
-//   in[2] : halo tile of the current / next 16-channel chunk, 64-B pixel records, 16-B slot s of pixel p stored at
-//           slot s ^ ((p>>2)&3)  -> ds_read_b128 of 16 consecutive pixels is bank-conflict free (256-B bank row)
-//   w[2]  : weights of the current / next stage, [n][16 k] records with the same swizzle (pre-applied by the packer,
-//           so staging is a linear 16-B copy)
-// Global->LDS staging goes through registers: loads for stage s+1 are issued before the MFMAs of stage s and written to
-// the other buffer after them (one barrier per stage).  Out-of-image halo pixels are written as zeros, which is exactly the
-// conv's zero padding because producers store the ACTIVATED tensor (see y_act below) -- the "pad after activation" rule
-// of the pre-activation block (AttResUNet.py:55,58).
+// Operand paths (r01 profile: a barrier per tap left the matrix pipe idle 27 % of the time -> weights left LDS):
+//   X (pixels)  : halo tile of one 16-channel chunk in LDS, 64-B pixel records, 16-B slot s of pixel p stored at slot
+//                 s ^ ((p>>2)&3) so a ds_read_b128 of 16 consecutive pixels is bank-conflict free.  Double-buffered: the
+//                 next chunk is loaded global->registers one piece per tap and written to the other buffer, ONE barrier
+//                 per chunk (KS*KS*MREP*NREP*8 MFMAs per wave between barriers).
+//   W (weights) : never staged in LDS.  The packer stores them in MFMA-fragment order so each wave reads its fragment for
+//                 the next half-step as coalesced 1-KB global_load_dwordx4 (L1/L2-resident: every workgroup reads the same
+//                 stream) straight into registers, one half-step ahead of use.
+//   Both fragments for half-step s+1 are requested before the MFMAs of half-step s are issued.
+// Out-of-image halo pixels are written as zeros, which is exactly the conv's zero padding because producers store the
+// ACTIVATED tensor (y_act below) -- the "pad after activation" rule of the pre-activation block (AttResUNet.py:55,58).
 //
-// Epilogue (per 32x32 block a lane holds ONE output channel for 16 pixels, so stores are 128-B channel runs):
+// Epilogue: weights are the MFMA row operand, so a lane ends up with 4 CONSECUTIVE output channels of one pixel per
+// accumulator quad -> residual loads and both stores are 16-B accesses:
 //   raw = acc + bias (+ residual)            -> y_raw
 //   act = lrelu(raw * mul[n,c] + add[n,c])   -> y_act   (what the next pre-activation conv consumes)
 //
 #include "common.h"
 #include "../../include/virnet_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -45,8 +49,8 @@ struct KArgs {
   float* y_raw;
   float* y_act;
   int N, H, W, Cin;        // input
-  int OH, OW;              // GEMM-M spatial extent (conv output; for CONVT the INPUT grid)
-  int NP;                  // padded GEMM-N
+  int OH, OW;              // GEMM pixel grid (conv output; for CONVT the INPUT grid)
+  int NP;                  // padded GEMM-N (output channel) extent
   int cout;                // real channels of the stored tensor
   int ntx, nty, ntiles, tiles_per_xcd;
   int epi, nchw_op, crop_h, crop_w, res_sf;
@@ -54,6 +58,9 @@ struct KArgs {
 };
 
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
+__device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
+  return f32x4{u.x > 0.f ? u.x : u.x * s, u.y > 0.f ? u.y : u.y * s, u.z > 0.f ? u.z : u.z * s, u.w > 0.f ? u.w : u.w * s};
+}
 
 template <int KS, int STRIDE, int MREP, int NREP>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
@@ -65,20 +72,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
   constexpr int NPIECE = NPIX * 4;                 // 16-B pieces of one input chunk
   constexpr int NTAPS = KS * KS;
   constexpr int PPT = (NPIECE + 255) / 256;        // input pieces per thread per chunk
-  constexpr int LPT = (PPT + NTAPS - 1) / NTAPS;   // ... issued per tap stage
+  constexpr int LPT = (PPT + NTAPS - 1) / NTAPS;   // ... issued per tap
   constexpr int NB = 32 * NREP;
-  constexpr int WPIECE = NB * 4;                   // 16-B pieces of one weight stage
-  constexpr int WPT = (WPIECE + 255) / 256;
   constexpr int IN_BYTES = NPIX * 64;
-  constexpr int W_BYTES = NB * 64;
+  constexpr int WSTEP = NREP * 256;                // floats of one half-step's weight fragments (NREP x 1 KB)
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const in_lds = smem;                       // [2][IN_BYTES]
-  char* const w_lds = smem + 2 * IN_BYTES;         // [2][W_BYTES]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // in[2][IN_BYTES]
 
   // ---- workgroup -> (tile, channel block).  Block b runs on XCD b%8 (observed, speed only): give every XCD a contiguous
-  // range of tiles so halo rows and the per-XCD weight working set stay in that XCD's L2, and keep the channel blocks of
-  // one tile adjacent in time so the input tile is fetched from HBM once.
+  // range of tiles so halo rows and the weight stream stay in that XCD's L2, and keep the channel blocks of one tile
+  // adjacent in time so the input tile is fetched from HBM once.
   const int ncb = a.NP / NB;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
@@ -96,36 +99,50 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int nchunks = a.Cin >> 4;
+  const int nsteps = nchunks * NTAPS * 2;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
-  const float* const wcb = a.wp + (size_t)cb * nchunks * NTAPS * (W_BYTES / 4);
+  const float* const wlane = a.wp + (size_t)cb * nsteps * WSTEP + lane * 4;
 
-  // ---- staging helpers -------------------------------------------------------------------------------------------
-  // input piece k of this thread: q = k*256+tid -> (pixel p, slot s)
-  auto in_piece = [&](int k, int chunk, f32x4& v, int& dst) {
+  // Input piece k of this thread: q = k*256+tid -> (pixel p, 16-B slot s).  The global load is ALWAYS issued, from an address
+  // clamped into the image; the zero fill of out-of-image halo pixels is applied when the registers are written to LDS, so
+  // nothing but the load writes its destination registers and no wait is needed before the MFMAs that hide its latency.
+  auto in_addr = [&](int k, int chunk, int& off, int& dst, bool& inb) {
     const int qq = k * 256 + tid;
-    dst = -1;
-    v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (k < PPT && qq < NPIECE) {
-      const int p = qq >> 2, s = qq & 3;
-      const int iy = p / IW, ix = p - iy * IW;
-      const int gy = iy0 + iy, gx = ix0 + ix;
-      dst = p * 64 + ((s ^ swz(p)) << 4);
-      if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-        v = *reinterpret_cast<const f32x4*>(ximg + ((size_t)(gy * a.W + gx) * a.Cin + chunk * 16 + s * 4));
+    const bool has = (k < PPT) && (qq < NPIECE);
+    const int qc = has ? qq : 0;
+    const int p = qc >> 2, s = qc & 3;
+    const int iy = p / IW, ix = p - iy * IW;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    inb = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+    off = (gyc * a.W + gxc) * a.Cin + chunk * 16 + s * 4;
+    dst = has ? p * 64 + ((s ^ swz(p)) << 4) : -1;
+  };
+  auto load_w = [&](int step, f32x4 (&b)[NREP]) {
+    const float* const p = wlane + (size_t)step * WSTEP;
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) b[nr] = *reinterpret_cast<const f32x4*>(p + nr * 256);
+  };
+  // pixel fragment of half-step (tap, j) for row block mr: 8 channels = slots 2j (lanes 0-31) / 2j+1 (lanes 32-63)
+  auto read_x = [&](const char* buf, int tap, int j, f32x4 (&x)[MREP]) {
+    const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
+#pragma unroll
+    for (int mr = 0; mr < MREP; ++mr) {
+      const int p = ((wave * MREP + mr) * STRIDE + dy) * IW + l31 * STRIDE + dx;
+      x[mr] = *reinterpret_cast<const f32x4*>(buf + p * 64 + (((2 * j + lhi) ^ swz(p)) << 4));
     }
   };
 
-  // ---- prologue: chunk 0 input + stage 0 weights ------------------------------------------------------------------
+  // ---- prologue: chunk 0 of the input tile -> LDS, weight fragment of half-step 0 -> registers ----------------------
+  f32x4 wcur[NREP];
+  load_w(0, wcur);
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    f32x4 v; int dst;
-    in_piece(k, 0, v, dst);
-    if (dst >= 0) *reinterpret_cast<f32x4*>(in_lds + dst) = v;
-  }
-#pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int qq = i * 256 + tid;
-    if (qq < WPIECE) *reinterpret_cast<f32x4*>(w_lds + qq * 16) = *reinterpret_cast<const f32x4*>(wcb + qq * 4);
+    int off, dst; bool inb;
+    in_addr(k, 0, off, dst, inb);
+    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + off);
+    if (!inb) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dst >= 0) *reinterpret_cast<f32x4*>(smem + dst) = v;
   }
   __syncthreads();
 
@@ -137,171 +154,143 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
 
-  // B-fragment byte offsets inside a weight stage (lane constants): record n = nr*32+l31, slot (2j+lhi)^swz(n)
-  const int bsw = swz(l31);
-  const int boff0 = l31 * 64 + (((0 + lhi) ^ bsw) << 4);
-  const int boff1 = l31 * 64 + (((2 + lhi) ^ bsw) << 4);
+  f32x4 xcur[MREP];
+  read_x(smem, 0, 0, xcur);
 
-  int stage = 0;
+  int step = 0;
   for (int c = 0; c < nchunks; ++c) {
-    const char* const in_cur = in_lds + (c & 1) * IN_BYTES;
-    char* const in_nxt = in_lds + ((c + 1) & 1) * IN_BYTES;
+    const char* const in_cur = smem + (c & 1) * IN_BYTES;
+    char* const in_nxt = smem + ((c + 1) & 1) * IN_BYTES;
     const bool more_chunks = (c + 1 < nchunks);
-#pragma unroll 1
-    for (int t = 0; t < NTAPS; ++t, ++stage) {
-      const bool more_stages = more_chunks || (t + 1 < NTAPS);
-      // ---- issue global loads for the next stage (weights) and a slice of the next chunk (input)
-      f32x4 wreg[WPT];
-      if (more_stages) {
-        const float* const wsrc = wcb + (size_t)(stage + 1) * (W_BYTES / 4);
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-          const int qq = i * 256 + tid;
-          if (qq < WPIECE) wreg[i] = *reinterpret_cast<const f32x4*>(wsrc + qq * 4);
-        }
-      }
+    for (int t = 0; t < NTAPS; ++t) {
       f32x4 ireg[LPT];
       int idst[LPT];
+      bool iinb[LPT];
 #pragma unroll
-      for (int i = 0; i < LPT; ++i) {
-        idst[i] = -1;
-        if (more_chunks) in_piece(t * LPT + i, c + 1, ireg[i], idst[i]);
-      }
-
-      // ---- MFMAs of this stage
-      const int dy = (KS == 3) ? t / 3 : 0;
-      const int dx = (KS == 3) ? t - dy * 3 : 0;
-      const char* const w_cur = w_lds + (stage & 1) * W_BYTES;
+      for (int j = 0; j < 2; ++j, ++step) {
+        const bool last_in_chunk = (t == NTAPS - 1) && (j == 1);
+        // ---- requests for half-step s+1 (weights: global -> regs, pixels: LDS -> regs) and one slice of the next chunk's
+        // input tile (global -> regs).  Always issued (the final ones re-read valid addresses): straight-line vmcnt.
+        f32x4 wnxt[NREP];
+        load_w(min(step + 1, nsteps - 1), wnxt);
+        if (j == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x4 af[MREP], bf[NREP];
-#pragma unroll
-        for (int mr = 0; mr < MREP; ++mr) {
-          const int p = ((wave * MREP + mr) * STRIDE + dy) * IW + l31 * STRIDE + dx;
-          af[mr] = *reinterpret_cast<const f32x4*>(in_cur + p * 64 + (((2 * j + lhi) ^ swz(p)) << 4));
+          for (int i = 0; i < LPT; ++i) {
+            int off;
+            in_addr(t * LPT + i, more_chunks ? c + 1 : c, off, idst[i], iinb[i]);
+            ireg[i] = *reinterpret_cast<const f32x4*>(ximg + off);
+          }
         }
-#pragma unroll
-        for (int nr = 0; nr < NREP; ++nr)
-          bf[nr] = *reinterpret_cast<const f32x4*>(w_cur + nr * 2048 + (j ? boff1 : boff0));
+        f32x4 xnxt[MREP];
+        if (!last_in_chunk) read_x(in_cur, j == 0 ? t : t + 1, j == 0 ? 1 : 0, xnxt);
+        // keep the requests ABOVE the MFMAs (hipcc otherwise sinks loads next to their first use and exposes their latency)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
             for (int nr = 0; nr < NREP; ++nr)
-              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mr][r], bf[nr][r], acc[mr][nr], 0, 0, 0);
-      }
-
-      // ---- land the prefetched data in the other buffers
-      if (more_stages) {
-        char* const w_nxt = w_lds + ((stage + 1) & 1) * W_BYTES;
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[nr][r], xcur[mr][r], acc[mr][nr], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 1 && more_chunks) {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-          const int qq = i * 256 + tid;
-          if (qq < WPIECE) *reinterpret_cast<f32x4*>(w_nxt + qq * 16) = wreg[i];
+          for (int i = 0; i < LPT; ++i)
+            if (idst[i] >= 0) *reinterpret_cast<f32x4*>(in_nxt + idst[i]) = iinb[i] ? ireg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int nr = 0; nr < NREP; ++nr) wcur[nr] = wnxt[nr];
+        if (!last_in_chunk) {
+#pragma unroll
+          for (int mr = 0; mr < MREP; ++mr) xcur[mr] = xnxt[mr];
         }
       }
-#pragma unroll
-      for (int i = 0; i < LPT; ++i)
-        if (idst[i] >= 0) *reinterpret_cast<f32x4*>(in_nxt + idst[i]) = ireg[i];
-      __syncthreads();
     }
+    __syncthreads();
+    if (more_chunks) read_x(in_nxt, 0, 0, xcur);
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------------------------
+  // ---- epilogue: lane = pixel (ox0 + l31), accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3) ----------
   const int nbase = cb * NB;
+  const int px = ox0 + l31;
   if (a.epi == VIRNET_EPI_NHWC) {
     const int C = a.cout;
     const size_t img_off = (size_t)img * a.OH * a.OW * C;
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
-      const int n = nbase + nr * 32 + l31;
-      const float bias = a.bias ? a.bias[n] : 0.f;
-      const float mul = a.mul ? a.mul[(size_t)img * C + n] : 1.f;
-      const float add = a.add ? a.add[(size_t)img * C + n] : 0.f;
 #pragma unroll
-      for (int mr = 0; mr < MREP; ++mr) {
-        const int oy = oy0 + wave * MREP + mr;
-        if (oy >= a.OH) continue;
-        const size_t row_off = img_off + (size_t)oy * a.OW * C + n;
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = nbase + nr * 32 + 8 * g + 4 * lhi;
+        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 mul = a.mul ? *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 add = a.add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (ox < a.OW) {
-            const size_t o = row_off + (size_t)ox * C;
-            float v = acc[mr][nr][r] + bias;
-            if (a.res) v += a.res[o];
-            if (a.y_raw) a.y_raw[o] = v;
-            if (a.y_act) {
-              const float u = fmaf(v, mul, add);
-              a.y_act[o] = u > 0.f ? u : u * a.slope;
-            }
+        for (int mr = 0; mr < MREP; ++mr) {
+          const int oy = oy0 + wave * MREP + mr;
+          if (oy < a.OH && px < a.OW) {
+            const size_t o = img_off + ((size_t)oy * a.OW + px) * C + c0;
+            f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias;
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
+            if (a.y_raw) *reinterpret_cast<f32x4*>(a.y_raw + o) = v;
+            if (a.y_act) *reinterpret_cast<f32x4*>(a.y_act + o) = lrelu4(v * mul + add, a.slope);
           }
         }
       }
     }
   } else if (a.epi == VIRNET_EPI_CONVT) {
-    // GEMM column n' = ab*cout + co ; pixel (iy,ix) -> output (2*iy+a, 2*ix+b)
+    // GEMM row n' = ab*cout + co ; input pixel (iy,ix) -> output pixel (2*iy+a, 2*ix+b)
     const int C = a.cout;
     const int OH2 = 2 * a.OH, OW2 = 2 * a.OW;
     const size_t img_off = (size_t)img * OH2 * OW2 * C;
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
-      const int np = nbase + nr * 32 + l31;
-      const int ab = np / C, co = np - ab * C;
-      const int ua = ab >> 1, ub = ab & 1;
-      const float bias = a.bias ? a.bias[co] : 0.f;
-      const float mul = a.mul ? a.mul[(size_t)img * C + co] : 1.f;
-      const float add = a.add ? a.add[(size_t)img * C + co] : 0.f;
 #pragma unroll
-      for (int mr = 0; mr < MREP; ++mr) {
-        const int iy = oy0 + wave * MREP + mr;
-        if (iy >= a.OH) continue;
-        const size_t row_off = img_off + (size_t)(2 * iy + ua) * OW2 * C + co;
+      for (int g = 0; g < 4; ++g) {
+        const int np = nbase + nr * 32 + 8 * g + 4 * lhi;
+        const int ab = np / C, co = np - ab * C;
+        const int ua = ab >> 1, ub = ab & 1;
+        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 mul = a.mul ? *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 add = a.add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + co) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ix = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (ix < a.OW) {
-            const size_t o = row_off + (size_t)(2 * ix + ub) * C;
-            float v = acc[mr][nr][r] + bias;
-            if (a.res) v += a.res[o];
-            if (a.y_raw) a.y_raw[o] = v;
-            if (a.y_act) {
-              const float u = fmaf(v, mul, add);
-              a.y_act[o] = u > 0.f ? u : u * a.slope;
-            }
+        for (int mr = 0; mr < MREP; ++mr) {
+          const int iy = oy0 + wave * MREP + mr;
+          if (iy < a.OH && px < a.OW) {
+            const size_t o = img_off + ((size_t)(2 * iy + ua) * OW2 + (2 * px + ub)) * C + co;
+            f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias;
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
+            if (a.y_raw) *reinterpret_cast<f32x4*>(a.y_raw + o) = v;
+            if (a.y_act) *reinterpret_cast<f32x4*>(a.y_act + o) = lrelu4(v * mul + add, a.slope);
           }
         }
       }
     }
-  } else {  // VIRNET_EPI_NCHW: few real channels (<= 32), planar store with crop
-    const int n = nbase + l31;
-    if (n < a.cout) {
+  } else {  // VIRNET_EPI_NCHW: few real channels (<= 32): planar store with crop; 32 consecutive x per channel = 128-B runs
+    const size_t plane = (size_t)a.crop_h * a.crop_w;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nbase + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (n >= a.cout) continue;
       const float bias = a.bias ? a.bias[n] : 0.f;
-      const size_t plane = (size_t)a.crop_h * a.crop_w;
       const size_t base = ((size_t)img * a.cout + n) * plane;
 #pragma unroll
       for (int mr = 0; mr < MREP; ++mr) {
         const int oy = oy0 + wave * MREP + mr;
-        if (oy >= a.crop_h) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (ox < a.crop_w) {
-            const size_t o = base + (size_t)oy * a.crop_w + ox;
-            float v = acc[mr][0][r] + bias;
-            if (a.nchw_op == VIRNET_NCHW_ADD) {
-              if (a.res_sf > 1) {
-                const int rw = a.crop_w / a.res_sf;
-                v += a.res[((size_t)img * a.cout + n) * (size_t)(a.crop_h / a.res_sf) * rw + (size_t)(oy / a.res_sf) * rw + ox / a.res_sf];
-              } else {
-                v += a.res[o];
-              }
-            } else if (a.nchw_op == VIRNET_NCHW_EXPCLAMP) {
-              v = expf(fminf(fmaxf(v, a.clamp_lo), a.clamp_hi));
+        if (oy < a.crop_h && px < a.crop_w) {
+          const size_t o = base + (size_t)oy * a.crop_w + px;
+          float v = acc[mr][0][r] + bias;
+          if (a.nchw_op == VIRNET_NCHW_ADD) {
+            if (a.res_sf > 1) {
+              const int rw = a.crop_w / a.res_sf;
+              v += a.res[((size_t)img * a.cout + n) * (size_t)(a.crop_h / a.res_sf) * rw + (size_t)(oy / a.res_sf) * rw + px / a.res_sf];
+            } else {
+              v += a.res[o];
             }
-            a.y_raw[o] = v;
+          } else if (a.nchw_op == VIRNET_NCHW_EXPCLAMP) {
+            v = expf(fminf(fmaxf(v, a.clamp_lo), a.clamp_hi));
           }
+          a.y_raw[o] = v;
         }
       }
     }
@@ -312,7 +301,7 @@ template <int KS, int STRIDE, int MREP, int NREP>
 int launch(const KArgs& ka, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
-  constexpr int LDS = 2 * IH * IW * 64 + 2 * 32 * NREP * 64;
+  constexpr int LDS = 2 * IH * IW * 64;
   static bool attr_done = false;
   auto kern = conv_mfma_kernel<KS, STRIDE, MREP, NREP>;
   if (!attr_done) {
@@ -340,7 +329,9 @@ int pick_nrep(int nblocks32) {
 
 // Small grids (deep U-Net levels, single images) use 4-row tiles so the 256 CUs still see >= 2 workgroups each.
 int pick_mrep(const virnet_conv_desc* d) {
-  if (d->stride == 2 || d->nrep == 7) return 1;
+  if (d->stride == 2 || d->nrep >= 4) return 1;   // MREP=2 with >= 4 channel blocks would spill (256-VGPR budget)
+  static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();  // tuning knob
+  if (forced == 1 || forced == 2) return forced;
   const int oh = d->h, ow = d->w;
   const long wg8 = (long)d->n * ((oh + 7) / 8) * ((ow + 31) / 32) * (d->n_pad / (32 * d->nrep));
   return wg8 < 2048 ? 1 : 2;
@@ -417,8 +408,8 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
       case 1: if (small) VIRNET_CASE(3, 1, 1, 1); else VIRNET_CASE(3, 1, 2, 1);
       case 2: if (small) VIRNET_CASE(3, 1, 1, 2); else VIRNET_CASE(3, 1, 2, 2);
       case 3: if (small) VIRNET_CASE(3, 1, 1, 3); else VIRNET_CASE(3, 1, 2, 3);
-      case 4: if (small) VIRNET_CASE(3, 1, 1, 4); else VIRNET_CASE(3, 1, 2, 4);
-      case 5: if (small) VIRNET_CASE(3, 1, 1, 5); else VIRNET_CASE(3, 1, 2, 5);
+      case 4: VIRNET_CASE(3, 1, 1, 4);
+      case 5: VIRNET_CASE(3, 1, 1, 5);
       case 7: VIRNET_CASE(3, 1, 1, 7);
     }
   } else if (d->ks == 3 && d->stride == 2) {
@@ -435,8 +426,8 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
       case 1: if (small) VIRNET_CASE(1, 1, 1, 1); else VIRNET_CASE(1, 1, 2, 1);
       case 2: if (small) VIRNET_CASE(1, 1, 1, 2); else VIRNET_CASE(1, 1, 2, 2);
       case 3: if (small) VIRNET_CASE(1, 1, 1, 3); else VIRNET_CASE(1, 1, 2, 3);
-      case 4: if (small) VIRNET_CASE(1, 1, 1, 4); else VIRNET_CASE(1, 1, 2, 4);
-      case 5: if (small) VIRNET_CASE(1, 1, 1, 5); else VIRNET_CASE(1, 1, 2, 5);
+      case 4: VIRNET_CASE(1, 1, 1, 4);
+      case 5: VIRNET_CASE(1, 1, 1, 5);
       case 7: VIRNET_CASE(1, 1, 1, 7);
     }
   }

@@ -11,21 +11,24 @@
 
 namespace {
 
+// Packed layout (matches conv_mfma.hip's load_w): [cb][chunk][tap][j][nr][lane][r], lane = lhi*32 + l31:
+//   output channel n = cb*32*nrep + nr*32 + l31, input channel ci = chunk*16 + 8*j + 4*lhi + r.
+// One half-step (cb, chunk, tap, j) is nrep contiguous 1-KB wave fragments.
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int kind, int cout, int cin, int ks,
                                    int cin_pad, int n_pad, int nrep, size_t total) {
-  const int NB = 32 * nrep;
   const int ntaps = ks * ks;
   const int nchunks = cin_pad / 16;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     size_t r = i;
-    const int kphys = (int)(r & 15); r >>= 4;
-    const int nl = (int)(r % NB); r /= NB;
+    const int rr = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int nr = (int)(r % nrep); r /= nrep;
+    const int j = (int)(r & 1); r >>= 1;
     const int t = (int)(r % ntaps); r /= ntaps;
     const int c = (int)(r % nchunks); r /= nchunks;
     const int cb = (int)r;
-    const int slot = (kphys >> 2) ^ ((nl >> 2) & 3);
-    const int ci = c * 16 + slot * 4 + (kphys & 3);
-    const int n = cb * NB + nl;
+    const int ci = c * 16 + 8 * j + 4 * (lane >> 5) + rr;
+    const int n = (cb * nrep + nr) * 32 + (lane & 31);
     float v = 0.f;
     if (ci < cin) {
       if (kind == 0) {
