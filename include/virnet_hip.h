@@ -71,8 +71,10 @@ typedef struct virnet_conv_desc {
   const float* res;    /* EPI_NHWC: NHWC [n][oh][ow][cout] residual (AttResUNet.py:59) or NULL
                           EPI_CONVT: NHWC [n][2h][2w][cout] bridge (AttResUNet.py:87) or NULL
                           EPI_NCHW : NCHW [n][cout][crop_h][crop_w] (the `+ x_in` of AttResUNet.py:173) or NULL */
-  const float* mul;    /* [n][cout] SFT scale for the activated copy (AttResUNet.py:54-58) or NULL (=1) */
-  const float* add;    /* [n][cout] SFT shift or NULL (=0) */
+  const float* mul;    /* [n][cout] SFT scale applied to y_act (AttResUNet.py:57-58) or NULL (=1) */
+  const float* add;    /* [n][cout] SFT shift applied to y_act or NULL (=0) */
+  const float* in_mul; /* [n][cin_pad] SFT scale applied to x while it is staged (AttResUNet.py:54-55) or NULL (=1) */
+  const float* in_add; /* [n][cin_pad] SFT shift applied to x while it is staged or NULL (=0) */
   float* y_raw;        /* conv + bias (+res); NULL = not stored */
   float* y_act;        /* leaky_relu(y_raw*mul+add, slope); NULL = not stored (EPI_NHWC / EPI_CONVT only) */
   int n, h, w;         /* input batch / spatial size */
@@ -86,6 +88,9 @@ typedef struct virnet_conv_desc {
   int crop_h, crop_w;  /* EPI_NCHW: stored extent (<= oh, ow) */
   int res_sf;          /* EPI_NCHW + VIRNET_NCHW_ADD: res is [n][cout][crop_h/res_sf][crop_w/res_sf] and is read through a
                           nearest x res_sf up-sampling (the x_up of VIRNet.py:83 added at AttResUNet.py:173); 0/1 = none */
+  int in_act;          /* 1: the conv consumes leaky_relu(x*in_mul+in_add, in_slope) -- the pre-activation of AttResUNet.py:55 --
+                          applied to the pixels on their way into LDS; padding stays zero AFTER the activation. 0: plain x */
+  float in_slope;      /* LeakyReLU slope of the input activation */
   float slope;         /* LeakyReLU slope of y_act */
   float clamp_lo, clamp_hi; /* VIRNET_NCHW_EXPCLAMP: y = exp(clamp(v, lo, hi))  (VIRNet.py:43) */
 } virnet_conv_desc;

@@ -75,6 +75,24 @@ def test_conv3x3_act_only_and_cross_channels():
     assert maxerr(nchw(raw2), raw_ref) <= TOL
 
 
+@pytest.mark.parametrize("c,h,w,n,sft", [(96, 17, 33, 2, False), (96, 12, 40, 2, True), (160, 9, 20, 1, True), (192, 16, 32, 2, False),
+                                          (288, 8, 32, 1, True), (64, 5, 70, 1, True)])
+def test_conv3x3_fused_preactivation(c, h, w, n, sft):
+    """AttResBlock conv1: conv(lrelu(x*mul1+add1)) with the activation applied while staging (AttResUNet.py:54-55), then
+    lrelu(.*mul2+add2) in the epilogue (AttResUNet.py:57-58).  x*mul+add != 0 at the border, so a wrong padding order shows."""
+    cp = make_conv(c, c)
+    x = rnd(n, c, h, w, seed=41)
+    mul1, add1 = rnd(n, c, seed=42, lo=0.2, hi=1.0), rnd(n, c, seed=43)
+    mul2, add2 = rnd(n, c, seed=44, lo=0.2, hi=1.0), rnd(n, c, seed=45)
+    a = x * mul1.view(n, c, 1, 1) + add1.view(n, c, 1, 1) if sft else x
+    raw_ref, act_ref = cpu_ref.conv_fused(F.leaky_relu(a, 0.2), cp.weight.detach(), cp.bias.detach(),
+                                          mul=mul2.view(n, c, 1, 1) if sft else None, add=add2.view(n, c, 1, 1) if sft else None)
+    cp.cuda()
+    kw = dict(in_mul=mul1.cuda(), in_add=add1.cuda(), mul=mul2.cuda(), add=add2.cuda()) if sft else {}
+    raw, act = ops.conv_mfma(nhwc(x), cp.packed(), in_slope=0.2, want_raw=True, want_act=True, slope=0.2, **kw)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+
+
 def test_zero_padding_is_applied_after_activation():
     """A constant field: border outputs must see zeros, not lrelu(add) (SURVEY.md 'pad-after-activation trap')."""
     cp = make_conv(64, 64)
@@ -84,6 +102,8 @@ def test_zero_padding_is_applied_after_activation():
     cp.cuda()
     raw, _ = ops.conv_mfma(nhwc(a), cp.packed())
     assert maxerr(nchw(raw), ref) <= TOL
+    raw2, _ = ops.conv_mfma(nhwc(x), cp.packed(), in_slope=0.2)     # same thing with the activation fused into the staging
+    assert maxerr(nchw(raw2), ref) <= TOL
 
 
 @pytest.mark.parametrize("cin,cout,h,w,n", [(96, 192, 16, 24, 2), (192, 288, 8, 64, 1), (96, 160, 10, 6, 1), (160, 224, 4, 68, 2),

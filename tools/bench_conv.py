@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single MFMA conv launches (tuning aid; VIRNET_HIP_LIB selects the build).
+
+    python tools/bench_conv.py [--shapes l0,l1,l2] [--iters 20]
+Shapes are the denoise-syn res-block convs at batch 32 x 256x256: l0 = 96ch@256^2, l1 = 192ch@128^2, l2 = 288ch@64^2.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from virnet_amd import ops  # noqa: E402
+from virnet_amd.networks.params import ConvParam  # noqa: E402
+
+SHAPES = {"l0": (32, 256, 256, 96), "l1": (32, 128, 128, 192), "l2": (32, 64, 64, 288), "s64": (32, 256, 256, 64),
+          "l0s": (64, 128, 128, 96), "one": (1, 484, 324, 96)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="l0,l1,l2")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--mode", default="dual", choices=["dual", "act", "raw"])
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    for name in args.shapes.split(","):
+        n, h, w, c = SHAPES[name]
+        cp = ConvParam(c, c, 3).cuda()
+        x = torch.rand(n, h, w, c, device="cuda") - 0.5
+        res = torch.rand(n, h, w, c, device="cuda") - 0.5
+        kw = dict(res=res, want_raw=True, want_act=True) if args.mode == "dual" else (
+            dict(want_raw=False, want_act=True) if args.mode == "act" else dict(want_raw=True, want_act=False))
+        pw = cp.packed()
+        for _ in range(3):
+            ops.conv_mfma(x, pw, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for _ in range(args.iters):
+            e0.record()
+            ops.conv_mfma(x, pw, **kw)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+        times.sort()
+        med = times[len(times) // 2]
+        flops = 2.0 * n * h * w * c * c * 9
+        print(f"{os.path.basename(os.environ.get('VIRNET_HIP_LIB', 'default')):24s} {name:4s} {args.mode:4s} median {med:8.3f} ms  "
+              f"min {times[0]:8.3f} ms  {flops / med / 1e9:7.2f} TFLOP/s (median)  {flops / times[0] / 1e9:7.2f} (best)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

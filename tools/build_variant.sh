@@ -1,0 +1,13 @@
+#!/bin/bash
+# tools/build_variant.sh NAME [extra hipcc flags] -> virnet_amd/lib/libvirnet_hip_NAME.so (tuning builds; not shipped)
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OBJ=$ROOT/build/variant_$NAME
+mkdir -p $OBJ
+for f in conv_mfma.hip pack.hip small.hip api.cpp; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip "$@" -c $ROOT/virnet_amd/csrc/$f -o $OBJ/${f%.*}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/virnet_amd/lib/libvirnet_hip_$NAME.so $OBJ/*.o
+echo built $NAME

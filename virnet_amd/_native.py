@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvirnet_hip.so")
+# VIRNET_HIP_LIB lets a tuning run point at another in-tree build of the same ABI (A/B kernel experiments)
+LIB_PATH = os.environ.get("VIRNET_HIP_LIB") or os.path.join(_HERE, "lib", "libvirnet_hip.so")
 ABI_VERSION = 1
 
 c_float_p = C.POINTER(C.c_float)
@@ -26,11 +27,12 @@ class ConvPlan(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("wpack", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
-        ("mul", C.c_void_p), ("add", C.c_void_p), ("y_raw", C.c_void_p), ("y_act", C.c_void_p),
+        ("mul", C.c_void_p), ("add", C.c_void_p), ("in_mul", C.c_void_p), ("in_add", C.c_void_p),
+        ("y_raw", C.c_void_p), ("y_act", C.c_void_p),
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int),
         ("n_pad", C.c_int), ("nrep", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("epi", C.c_int),
         ("nchw_op", C.c_int), ("crop_h", C.c_int), ("crop_w", C.c_int), ("res_sf", C.c_int),
-        ("slope", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+        ("in_act", C.c_int), ("in_slope", C.c_float), ("slope", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
     ]
 
 

@@ -10,25 +10,28 @@
 // chain), so parity with the reference's fp32 conv is at re-association level (~1e-6), far inside the 1e-3 contract.
 //
 // Workgroup = 4 waves = (4*MREP) output rows x 32 output columns x NB=32*NREP output channels; wave w owns rows
-// [w*MREP, (w+1)*MREP); one MFMA column block is 32 consecutive pixels of a row.  K is walked as 16-channel chunks x KS*KS
-// taps x 2 half-steps of 8 channels; per half-step a wave issues MREP*NREP*4 MFMAs.
+// [w*MREP, (w+1)*MREP) x all NB channels (MREP x NREP accumulator blocks of 32x32); one MFMA column block is 32 consecutive
+// pixels of a row.  K is walked as 16-channel chunks x KS*KS taps x 2 half-steps of 8 channels; a wave issues MREP*NREP*4
+// MFMAs per half-step.
 //
-// Operand paths (r01 profile: a barrier per tap left the matrix pipe idle 27 % of the time -> weights left LDS):
-//   X (pixels)  : halo tile of one 16-channel chunk in LDS, 64-B pixel records, 16-B slot s of pixel p stored at slot
-//                 s ^ ((p>>2)&3) so a ds_read_b128 of 16 consecutive pixels is bank-conflict free.  Double-buffered: the
-//                 next chunk is loaded global->registers one piece per tap and written to the other buffer, ONE barrier
-//                 per chunk (KS*KS*MREP*NREP*8 MFMAs per wave between barriers).
-//   W (weights) : never staged in LDS.  The packer stores them in MFMA-fragment order so each wave reads its fragment for
-//                 the next half-step as coalesced 1-KB global_load_dwordx4 (L1/L2-resident: every workgroup reads the same
-//                 stream) straight into registers, one half-step ahead of use.
-//   Both fragments for half-step s+1 are requested before the MFMAs of half-step s are issued.
-// Out-of-image halo pixels are written as zeros, which is exactly the conv's zero padding because producers store the
-// ACTIVATED tensor (y_act below) -- the "pad after activation" rule of the pre-activation block (AttResUNet.py:55,58).
+// Operand paths.  Both MFMA operands are read from LDS as ds_read_b128 fragments, one half-step ahead of the MFMAs that use
+// them.  (Round-1 profiling on MI355X: fragments loaded straight from global memory cost ~16 matrix-pipe cycles per returned
+// VGPR row -- L1-hot or not, consumed or not -- against ~3-6 for LDS returns; see DESIGN.md "what the probes showed".)
+//   X (pixels)  : halo tile of one 16-channel chunk, 64-B pixel records, 16-B slot s of pixel p stored at slot s ^ ((p>>2)&3)
+//                 so a ds_read_b128 of 16 consecutive pixels is bank-conflict free.  Two buffers: the next chunk is fetched
+//                 global->registers one 16-B piece per thread per tap and written to the other buffer.
+//   W (weights) : a 3-slot ring of per-tap stages ([j][nr][lane][16 B], exactly the packed global image, so staging is a
+//                 linear copy and fragment reads are conflict free).  Stage s+2 is fetched during tap s and landed at its end,
+//                 so after the per-tap barrier the fragments of tap s+1 are already in LDS and already requested.
+//   The staging loads are issued before a tap's MFMAs and consumed after them; nothing else writes their registers, so no
+//   s_waitcnt separates them from the MFMAs that hide their latency.
+// Pre-activation (AttResUNet.py:54-55): lrelu(x*mul+add) is applied to the pixel pieces on their way into LDS, out-of-image
+// halo pixels are zeroed AFTER it -- the conv's zero padding applies to the activated tensor ("pad after activation").
 //
 // Epilogue: weights are the MFMA row operand, so a lane ends up with 4 CONSECUTIVE output channels of one pixel per
-// accumulator quad -> residual loads and both stores are 16-B accesses:
+// accumulator quad -> residual loads and stores are 16-B accesses:
 //   raw = acc + bias (+ residual)            -> y_raw
-//   act = lrelu(raw * mul[n,c] + add[n,c])   -> y_act   (what the next pre-activation conv consumes)
+//   act = lrelu(raw * mul[n,c] + add[n,c])   -> y_act   (stored instead of raw when only the activated tensor is consumed)
 //
 #include "common.h"
 #include "../../include/virnet_hip.h"
@@ -46,6 +49,8 @@ struct KArgs {
   const float* res;
   const float* mul;
   const float* add;
+  const float* in_mul;
+  const float* in_add;
   float* y_raw;
   float* y_act;
   int N, H, W, Cin;        // input
@@ -53,8 +58,8 @@ struct KArgs {
   int NP;                  // padded GEMM-N (output channel) extent
   int cout;                // real channels of the stored tensor
   int ntx, nty, ntiles, tiles_per_xcd;
-  int epi, nchw_op, crop_h, crop_w, res_sf;
-  float slope, clamp_lo, clamp_hi;
+  int epi, nchw_op, crop_h, crop_w, res_sf, in_act;
+  float in_slope, slope, clamp_lo, clamp_hi;
 };
 
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
@@ -75,9 +80,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
   constexpr int LPT = (PPT + NTAPS - 1) / NTAPS;   // ... issued per tap
   constexpr int NB = 32 * NREP;
   constexpr int IN_BYTES = NPIX * 64;
-  constexpr int WSTEP = NREP * 256;                // floats of one half-step's weight fragments (NREP x 1 KB)
+  constexpr int WSTAGE = NREP * 2048;              // bytes of one tap's weight fragments: [j][nr][lane][16 B]
+  constexpr int WPIECE = NREP * 128;               // ... in 16-B pieces
+  constexpr int WPT = (WPIECE + 255) / 256;
+  constexpr int RING = 3;                          // weight ring slots (NTAPS % RING == 0 or NTAPS == 1)
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // in[2][IN_BYTES]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const x_lds = smem;                        // [2][IN_BYTES]   pixel tile of chunk c / c+1
+  char* const w_lds = smem + 2 * IN_BYTES;         // [RING][WSTAGE]  weight fragments of taps s, s+1, s+2
 
   // ---- workgroup -> (tile, channel block).  Block b runs on XCD b%8 (observed, speed only): give every XCD a contiguous
   // range of tiles so halo rows and the weight stream stay in that XCD's L2, and keep the channel blocks of one tile
@@ -99,9 +109,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int nchunks = a.Cin >> 4;
-  const int nsteps = nchunks * NTAPS * 2;
+  const int nstages = nchunks * NTAPS;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
-  const float* const wlane = a.wp + (size_t)cb * nsteps * WSTEP + lane * 4;
+  const float* const wcb = a.wp + (size_t)cb * nstages * (WSTAGE / 4);
 
   // Input piece k of this thread: q = k*256+tid -> (pixel p, 16-B slot s).  The global load is ALWAYS issued, from an address
   // clamped into the image; the zero fill of out-of-image halo pixels is applied when the registers are written to LDS, so
@@ -118,12 +128,36 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
     off = (gyc * a.W + gxc) * a.Cin + chunk * 16 + s * 4;
     dst = has ? p * 64 + ((s ^ swz(p)) << 4) : -1;
   };
-  auto load_w = [&](int step, f32x4 (&b)[NREP]) {
-    const float* const p = wlane + (size_t)step * WSTEP;
-#pragma unroll
-    for (int nr = 0; nr < NREP; ++nr) b[nr] = *reinterpret_cast<const f32x4*>(p + nr * 256);
+  // Pre-activation on the way into LDS (AttResUNet.py:54-55): v -> lrelu(v*mul+add), then zero for out-of-image pixels, so
+  // the conv's zero padding applies to the ACTIVATED tensor.  A thread's pieces always sit in slot tid&3 of their pixel, so
+  // its 4 channels of chunk c are c*16 + 4*(tid&3) + (0..3): one scale/shift quad per chunk.
+  const bool in_sft = a.in_mul != nullptr;
+  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + 4 * (tid & 3) : nullptr;
+  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + 4 * (tid & 3) : nullptr;
+  auto stage_x = [&](f32x4 v, bool inb, const f32x4& m4, const f32x4& a4) -> f32x4 {
+    if (a.in_act) {
+      if (in_sft) v = v * m4 + a4;
+      v = lrelu4(v, a.in_slope);
+    }
+    return inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // pixel fragment of half-step (tap, j) for row block mr: 8 channels = slots 2j (lanes 0-31) / 2j+1 (lanes 32-63)
+  // weight stage `stage` -> registers (linear 16-B pieces; the packed global image IS the LDS image)
+  auto load_w = [&](int stage, f32x4 (&r)[WPT]) {
+    const float* const p = wcb + (size_t)stage * (WSTAGE / 4);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + min(i * 256 + tid, WPIECE - 1) * 4);
+  };
+  auto store_w = [&](int slot, const f32x4 (&r)[WPT]) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      if (i * 256 + tid < WPIECE) *reinterpret_cast<f32x4*>(w_lds + slot * WSTAGE + (i * 256 + tid) * 16) = r[i];
+  };
+  // fragments of half-step (tap, j): weights of ring slot `slot`, pixels of tile buffer `buf`
+  auto read_w = [&](int slot, int j, f32x4 (&w)[NREP]) {
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr)
+      w[nr] = *reinterpret_cast<const f32x4*>(w_lds + slot * WSTAGE + (j * NREP + nr) * 1024 + lane * 16);
+  };
   auto read_x = [&](const char* buf, int tap, int j, f32x4 (&x)[MREP]) {
     const int dy = (KS == 3) ? tap / 3 : 0, dx = (KS == 3) ? tap % 3 : 0;
 #pragma unroll
@@ -133,16 +167,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
     }
   };
 
-  // ---- prologue: chunk 0 of the input tile -> LDS, weight fragment of half-step 0 -> registers ----------------------
-  f32x4 wcur[NREP];
-  load_w(0, wcur);
+  // ---- prologue: chunk 0 of the pixel tile and weight stages 0, 1 -> LDS -------------------------------------------------
+  {
+    f32x4 w0[WPT], w1[WPT];
+    load_w(0, w0);
+    load_w(min(1, nstages - 1), w1);
 #pragma unroll
-  for (int k = 0; k < PPT; ++k) {
-    int off, dst; bool inb;
-    in_addr(k, 0, off, dst, inb);
-    f32x4 v = *reinterpret_cast<const f32x4*>(ximg + off);
-    if (!inb) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (dst >= 0) *reinterpret_cast<f32x4*>(smem + dst) = v;
+    for (int k = 0; k < PPT; ++k) {
+      int off, dst; bool inb;
+      in_addr(k, 0, off, dst, inb);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ximg + off);
+      const f32x4 m4 = in_sft ? *reinterpret_cast<const f32x4*>(imul) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 a4 = in_sft ? *reinterpret_cast<const f32x4*>(iadd) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dst >= 0) *reinterpret_cast<f32x4*>(x_lds + dst) = stage_x(v, inb, m4, a4);
+    }
+    store_w(0, w0);
+    store_w(1 % RING, w1);
   }
   __syncthreads();
 
@@ -154,37 +194,50 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
 
-  f32x4 xcur[MREP];
-  read_x(smem, 0, 0, xcur);
+  f32x4 wcur[NREP], xcur[MREP];
+  read_w(0, 0, wcur);
+  read_x(x_lds, 0, 0, xcur);
 
-  int step = 0;
+  int stage = 0;
   for (int c = 0; c < nchunks; ++c) {
-    const char* const in_cur = smem + (c & 1) * IN_BYTES;
-    char* const in_nxt = smem + ((c + 1) & 1) * IN_BYTES;
+    const char* const in_cur = x_lds + (c & 1) * IN_BYTES;
+    char* const in_nxt = x_lds + ((c + 1) & 1) * IN_BYTES;
     const bool more_chunks = (c + 1 < nchunks);
+    f32x4 m4 = f32x4{1.f, 1.f, 1.f, 1.f}, a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in_sft && more_chunks) {
+      m4 = *reinterpret_cast<const f32x4*>(imul + (c + 1) * 16);
+      a4 = *reinterpret_cast<const f32x4*>(iadd + (c + 1) * 16);
+    }
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
+    for (int t = 0; t < NTAPS; ++t, ++stage) {
+      // ring slots: NTAPS == 9 is a multiple of RING, so the slot of tap t is a compile-time t % RING
+      const int slot = (NTAPS % RING == 0) ? t % RING : stage % RING;
+      const int slot1 = (slot + 1) % RING, slot2 = (slot + 2) % RING;
+      const bool last_tap = (t == NTAPS - 1);
+      // ---- staging requests (global -> regs): weights of stage s+2, one slice of the next chunk's pixel tile.  Always
+      // issued (the final ones re-read valid addresses) so the memory counters see straight-line code.
+      f32x4 wreg[WPT];
+      load_w(min(stage + 2, nstages - 1), wreg);
       f32x4 ireg[LPT];
       int idst[LPT];
       bool iinb[LPT];
 #pragma unroll
-      for (int j = 0; j < 2; ++j, ++step) {
-        const bool last_in_chunk = (t == NTAPS - 1) && (j == 1);
-        // ---- requests for half-step s+1 (weights: global -> regs, pixels: LDS -> regs) and one slice of the next chunk's
-        // input tile (global -> regs).  Always issued (the final ones re-read valid addresses): straight-line vmcnt.
-        f32x4 wnxt[NREP];
-        load_w(min(step + 1, nsteps - 1), wnxt);
-        if (j == 0) {
+      for (int i = 0; i < LPT; ++i) {
+        int off;
+        in_addr(t * LPT + i, more_chunks ? c + 1 : c, off, idst[i], iinb[i]);
+        ireg[i] = *reinterpret_cast<const f32x4*>(ximg + off);
+      }
 #pragma unroll
-          for (int i = 0; i < LPT; ++i) {
-            int off;
-            in_addr(t * LPT + i, more_chunks ? c + 1 : c, off, idst[i], iinb[i]);
-            ireg[i] = *reinterpret_cast<const f32x4*>(ximg + off);
-          }
+      for (int j = 0; j < 2; ++j) {
+        // ---- fragment requests (LDS -> regs) for the NEXT half-step, issued before this half-step's MFMAs
+        f32x4 wnxt[NREP], xnxt[MREP];
+        if (j == 0) {
+          read_w(slot, 1, wnxt);
+          read_x(in_cur, t, 1, xnxt);
+        } else {
+          read_w(slot1, 0, wnxt);                               // stage s+1 was landed one tap ago
+          if (!last_tap) read_x(in_cur, t + 1, 0, xnxt);        // (next chunk's pixels become visible after the barrier)
         }
-        f32x4 xnxt[MREP];
-        if (!last_in_chunk) read_x(in_cur, j == 0 ? t : t + 1, j == 0 ? 1 : 0, xnxt);
-        // keep the requests ABOVE the MFMAs (hipcc otherwise sinks loads next to their first use and exposes their latency)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -194,79 +247,79 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
             for (int nr = 0; nr < NREP; ++nr)
               acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[nr][r], xcur[mr][r], acc[mr][nr], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (j == 1 && more_chunks) {
-#pragma unroll
-          for (int i = 0; i < LPT; ++i)
-            if (idst[i] >= 0) *reinterpret_cast<f32x4*>(in_nxt + idst[i]) = iinb[i] ? ireg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 #pragma unroll
         for (int nr = 0; nr < NREP; ++nr) wcur[nr] = wnxt[nr];
-        if (!last_in_chunk) {
+        if (!(j == 1 && last_tap)) {
 #pragma unroll
           for (int mr = 0; mr < MREP; ++mr) xcur[mr] = xnxt[mr];
         }
       }
+      // ---- land the staged data: weights of stage s+2 into the slot last read during tap s-1, pixels into the other tile
+      store_w(slot2, wreg);
+      if (more_chunks) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i)
+          if (idst[i] >= 0) *reinterpret_cast<f32x4*>(in_nxt + idst[i]) = stage_x(ireg[i], iinb[i], m4, a4);
+      }
+      __syncthreads();
+      if (last_tap && more_chunks) read_x(in_nxt, 0, 0, xcur);
     }
-    __syncthreads();
-    if (more_chunks) read_x(in_nxt, 0, 0, xcur);
   }
 
   // ---- epilogue: lane = pixel (ox0 + l31), accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3) ----------
+  // Addressing: a wave-uniform 64-bit image base (SGPRs) + ONE 32-bit offset per row block + compile-time immediates.
   const int nbase = cb * NB;
   const int px = ox0 + l31;
-  if (a.epi == VIRNET_EPI_NHWC) {
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (KS == 1 || a.epi != VIRNET_EPI_NCHW) {
+    // NHWC store, or (KS == 1) the transposed conv's depth-to-space store: GEMM row n' = ab*cout + co and input pixel
+    // (iy,ix) -> output pixel (2*iy+a, 2*ix+b), channel co.
+    const bool convt = (KS == 1) && a.epi == VIRNET_EPI_CONVT;
     const int C = a.cout;
-    const size_t img_off = (size_t)img * a.OH * a.OW * C;
+    const int OWs = convt ? 2 * a.OW : a.OW;
+    const size_t img_off = (size_t)img * (convt ? 4 : 1) * a.OH * a.OW * C;
+    const float* const rimg = a.res ? a.res + img_off : nullptr;
+    float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+    float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+    const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
+    const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
+    unsigned eo[MREP];
+    bool ok[MREP];
+#pragma unroll
+    for (int mr = 0; mr < MREP; ++mr) {
+      const int oy = oy0 + wave * MREP + mr;
+      ok[mr] = oy < a.OH && px < a.OW;
+      eo[mr] = convt ? (unsigned)((2 * oy) * OWs + 2 * px) * (unsigned)C : (unsigned)(oy * OWs + px) * (unsigned)C;
+    }
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c0 = nbase + nr * 32 + 8 * g + 4 * lhi;
-        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 mul = a.mul ? *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 add = a.add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int np = nbase + nr * 32 + 8 * g + 4 * lhi;      // GEMM row of this quad
+        int co = np;
+        unsigned shift = 0;
+        if (convt) {
+          const int ab = np / C;
+          co = np - ab * C;
+          shift = (unsigned)((ab >> 1) * OWs + (ab & 1)) * (unsigned)C;
+        }
+        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
+        const f32x4 mul = mulp ? *reinterpret_cast<const f32x4*>(mulp + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 add = addp ? *reinterpret_cast<const f32x4*>(addp + co) : zero4;
 #pragma unroll
         for (int mr = 0; mr < MREP; ++mr) {
-          const int oy = oy0 + wave * MREP + mr;
-          if (oy < a.OH && px < a.OW) {
-            const size_t o = img_off + ((size_t)oy * a.OW + px) * C + c0;
+          if (ok[mr]) {
+            const unsigned o = eo[mr] + shift + (unsigned)co;
             f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias;
-            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
-            if (a.y_raw) *reinterpret_cast<f32x4*>(a.y_raw + o) = v;
-            if (a.y_act) *reinterpret_cast<f32x4*>(a.y_act + o) = lrelu4(v * mul + add, a.slope);
+            if (rimg) v += *reinterpret_cast<const f32x4*>(rimg + o);
+            if (yraw) *reinterpret_cast<f32x4*>(yraw + o) = v;
+            if (yact) *reinterpret_cast<f32x4*>(yact + o) = lrelu4(v * mul + add, a.slope);
           }
         }
       }
     }
-  } else if (a.epi == VIRNET_EPI_CONVT) {
-    // GEMM row n' = ab*cout + co ; input pixel (iy,ix) -> output pixel (2*iy+a, 2*ix+b)
-    const int C = a.cout;
-    const int OH2 = 2 * a.OH, OW2 = 2 * a.OW;
-    const size_t img_off = (size_t)img * OH2 * OW2 * C;
-#pragma unroll
-    for (int nr = 0; nr < NREP; ++nr) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int np = nbase + nr * 32 + 8 * g + 4 * lhi;
-        const int ab = np / C, co = np - ab * C;
-        const int ua = ab >> 1, ub = ab & 1;
-        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 mul = a.mul ? *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + co) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 add = a.add ? *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int mr = 0; mr < MREP; ++mr) {
-          const int iy = oy0 + wave * MREP + mr;
-          if (iy < a.OH && px < a.OW) {
-            const size_t o = img_off + ((size_t)(2 * iy + ua) * OW2 + (2 * px + ub)) * C + co;
-            f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias;
-            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
-            if (a.y_raw) *reinterpret_cast<f32x4*>(a.y_raw + o) = v;
-            if (a.y_act) *reinterpret_cast<f32x4*>(a.y_act + o) = lrelu4(v * mul + add, a.slope);
-          }
-        }
-      }
-    }
-  } else {  // VIRNET_EPI_NCHW: few real channels (<= 32): planar store with crop; 32 consecutive x per channel = 128-B runs
+  } else if (NREP == 1) {
+    // VIRNET_EPI_NCHW: few real channels (<= 32): planar store with crop; 32 consecutive x per channel = 128-B runs
     const size_t plane = (size_t)a.crop_h * a.crop_w;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -301,7 +354,7 @@ template <int KS, int STRIDE, int MREP, int NREP>
 int launch(const KArgs& ka, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
-  constexpr int LDS = 2 * IH * IW * 64;
+  constexpr int LDS = 2 * IH * IW * 64 + 3 * NREP * 2048;
   static bool attr_done = false;
   auto kern = conv_mfma_kernel<KS, STRIDE, MREP, NREP>;
   if (!attr_done) {
@@ -364,8 +417,11 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   VIRNET_REQUIRE(d->cin_pad > 0 && d->cin_pad % 16 == 0, "virnet_conv_mfma: cin_pad=%d is not a multiple of 16", d->cin_pad);
   VIRNET_REQUIRE(d->nrep >= 1 && d->n_pad % (32 * d->nrep) == 0, "virnet_conv_mfma: n_pad=%d not a multiple of 32*nrep (nrep=%d)",
                  d->n_pad, d->nrep);
+  VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_mfma: in_mul and in_add must be given together");
+  VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_mfma: in_mul/in_add without in_act");
   KArgs k{};
   k.x = d->x; k.wp = d->wpack; k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
+  k.in_mul = d->in_mul; k.in_add = d->in_add; k.in_act = d->in_act; k.in_slope = d->in_slope;
   k.y_raw = d->y_raw; k.y_act = d->y_act;
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad;
   k.NP = d->n_pad; k.cout = d->cout;
@@ -379,6 +435,7 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   }
   switch (d->epi) {
     case VIRNET_EPI_NHWC:
+      VIRNET_REQUIRE(d->ks == 3, "virnet_conv_mfma: NHWC store is built for the 3x3 kernels (ks=%d)", d->ks);
       VIRNET_REQUIRE(d->n_pad == d->cout, "virnet_conv_mfma: NHWC store needs cout (%d) to be a multiple of 32", d->cout);
       VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_mfma: no output pointer");
       break;

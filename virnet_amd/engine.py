@@ -1,9 +1,12 @@
-"""Forward orchestration: which kernel runs when, with which fused epilogue.
+"""Forward orchestration: which kernel runs when, with which fused prologue/epilogue.
 
-Every pre-activation conv of the reference (``conv(lrelu(x*mul+add))``, networks/AttResUNet.py:55,58) reads a tensor that
-its PRODUCER already stored activated: each MFMA conv can store ``raw`` (what residual adds and the stride-2 / transposed
-convs consume) and/or ``act = lrelu(raw*mul+add)`` (what the next 3x3 consumes).  So the conv kernel itself sees plain
-zero-padded input -- "pad after activation" holds by construction -- and no elementwise kernel runs between convs.
+Every MFMA conv stores exactly ONE tensor.  The reference's pre-activation convs (``conv(lrelu(x*mul+add))``,
+networks/AttResUNet.py:55,58) are served two ways, both inside the conv kernel:
+  * a tensor that is also needed raw (the residual stream x: AttResUNet.py:59, the bridges, the stride-2 / transposed convs) is
+    stored raw, and the consuming conv applies LeakyReLU (and the SFT scale/shift) while it stages the pixels into LDS;
+  * a tensor only ever consumed activated (conv1's output, the DnCNN / KNet post-activation features) is stored activated by
+    its producer's epilogue.
+Either way the zero padding applies to the ACTIVATED tensor ("pad after activation") and no elementwise kernel runs between convs.
 
 Python here only sequences launches on torch's current stream and owns the buffers; there is no CPU path.
 """
@@ -88,28 +91,24 @@ class _Cond:
     def __init__(self, vec: Optional[Tensor], rec: Optional[Tensor], chan0: int, nchan: int):
         self.vec, self.rec, self.chan0, self.nchan = vec, rec, chan0, nchan
 
-    def params(self, att) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-        if self.vec is None:
-            return None, None
-        return ops.sft_vec(self.vec, att)
 
-
-def _produce(x: Tensor, conv, cond: Optional[_Cond], att, level: int, *, stride: int = 1, res: Optional[Tensor] = None,
-             want_raw: bool, want_act: bool = True) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """Run one MFMA conv and deliver (raw, act) where act is what the next pre-activation conv reads.
-
-    ``att`` is the AttLayer of the CONSUMER of ``act`` (None -> plain LeakyReLU(0.2))."""
-    pw = conv.packed()
-    if not want_act:
-        return ops.conv_mfma(x, pw, stride=stride, res=res, want_raw=True, want_act=False)
-    if att is None or cond is None:
-        return ops.conv_mfma(x, pw, stride=stride, res=res, want_raw=want_raw, want_act=True, slope=0.2)
-    if cond.vec is not None:   # spatially constant conditioning: SFT collapses to per-(image, channel) scale/shift
-        mul, add = cond.params(att)
-        return ops.conv_mfma(x, pw, stride=stride, res=res, mul=mul, add=add, want_raw=want_raw, want_act=True, slope=0.2)
-    raw, _ = ops.conv_mfma(x, pw, stride=stride, res=res, want_raw=True, want_act=False)
-    act = ops.sft_apply(raw, cond.rec, cond.chan0, cond.nchan, 1 << level, att)
-    return (raw if want_raw else None), act
+def _res_block(x_raw: Tensor, blk, cond: Optional[_Cond], level: int) -> Tensor:
+    """AttResBlock.forward (AttResUNet.py:48-60): x + conv2(lrelu(sft2(conv1(lrelu(sft1(x)))))), two launches."""
+    sft = cond is not None and blk.extra_chn > 0
+    c1, c2 = blk.conv1.packed(), blk.conv2.packed()
+    if not sft:
+        _, f1a = ops.conv_mfma(x_raw, c1, in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
+    elif cond.vec is not None:   # spatially constant conditioning: SFT collapses to per-(image, channel) scale/shift
+        mul1, add1 = ops.sft_vec(cond.vec, blk.sft1)
+        mul2, add2 = ops.sft_vec(cond.vec, blk.sft2)
+        _, f1a = ops.conv_mfma(x_raw, c1, in_slope=0.2, in_mul=mul1, in_add=add1, mul=mul2, add=add2, want_raw=False,
+                               want_act=True, slope=0.2)
+    else:                        # per-pixel conditioning: materialise the two modulated tensors (rare configuration)
+        a1 = ops.sft_apply(x_raw, cond.rec, cond.chan0, cond.nchan, 1 << level, blk.sft1)
+        f1, _ = ops.conv_mfma(a1, c1, want_raw=True)
+        f1a = ops.sft_apply(f1, cond.rec, cond.chan0, cond.nchan, 1 << level, blk.sft2)
+    out, _ = ops.conv_mfma(f1a, c2, res=x_raw, want_raw=True)
+    return out
 
 
 def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extra_vec: Optional[Tensor] = None,
@@ -144,35 +143,19 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
                                                         map_sf=map_sf, map_sqrt=map_sqrt)
             cond = _Cond(None, crec, rnet.in_chn, ev + em)
 
-    def sft(block, which):
-        return getattr(block, which) if (cond is not None and block.extra_chn > 0) else None
-
-    down = rnet.down_path
-    first = down[0].body[0] if len(down[0].body) else None
-    x_raw, x_act = _produce(rec, rnet.head, cond, sft(first, "sft1") if first is not None else None, 0,
-                            want_raw=True, want_act=first is not None)
+    x, _ = ops.conv_mfma(rec, rnet.head.packed(), want_raw=True)                       # AttResUNet.py:153-155
     bridges: List[Tensor] = []
-    for ii, lvl in enumerate(down):
-        nb = len(lvl.body)
-        for jj, blk in enumerate(lvl.body):
-            _, f1a = _produce(x_act, blk.conv1, cond, sft(blk, "sft2"), ii, want_raw=False)
-            nxt = lvl.body[jj + 1] if jj + 1 < nb else None
-            x_raw, x_act = _produce(f1a, blk.conv2, cond, sft(nxt, "sft1") if nxt is not None else None, ii, res=x_raw,
-                                    want_raw=True, want_act=nxt is not None)
-        if ii + 1 < len(down):
-            bridges.append(x_raw)
-            nlvl = down[ii + 1]
-            nfirst = nlvl.body[0] if len(nlvl.body) else None
-            x_raw, x_act = _produce(x_raw, lvl.downsampler, cond, sft(nfirst, "sft1") if nfirst is not None else None,
-                                    ii + 1, stride=2, want_raw=True, want_act=nfirst is not None)
+    for ii, lvl in enumerate(rnet.down_path):
+        for blk in lvl.body:
+            x = _res_block(x, blk, cond, ii)
+        if ii + 1 < len(rnet.down_path):
+            bridges.append(x)
+            x, _ = ops.conv_mfma(x, lvl.downsampler.packed(), stride=2, want_raw=True)   # AttResUNet.py:67,74
     for jj, up in enumerate(rnet.up_path):
-        nb = len(up.body)
-        x_raw, x_act = ops.conv_mfma(x_raw, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True, want_act=nb > 0,
-                                     slope=0.2)
-        for kk, blk in enumerate(up.body):
-            _, f1a = ops.conv_mfma(x_act, blk.conv1.packed(), want_raw=False, want_act=True, slope=0.2)
-            x_raw, x_act = ops.conv_mfma(f1a, blk.conv2.packed(), res=x_raw, want_raw=True, want_act=kk + 1 < nb, slope=0.2)
-    return ops.conv_mfma_nchw(x_raw, rnet.tail.packed(), (H, W), op=nat.NCHW_ADD, res=x_in, res_sf=sf)
+        x, _ = ops.conv_mfma(x, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True)   # AttResUNet.py:84-87
+        for blk in up.body:
+            x = _res_block(x, blk, None, 0)
+    return ops.conv_mfma_nchw(x, rnet.tail.packed(), (H, W), op=nat.NCHW_ADD, res=x_in, res_sf=sf)   # AttResUNet.py:173
 
 
 # ----------------------------------------------------------------------------------------------------------------

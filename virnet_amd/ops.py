@@ -117,8 +117,12 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
 
 def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
               mul: Optional[Tensor] = None, add: Optional[Tensor] = None, want_raw: bool = True,
-              want_act: bool = False, slope: float = 0.2) -> Tuple[Optional[Tensor], Optional[Tensor]]:
-    """NHWC conv (or transposed conv when ``pw.transposed``) -> (raw, act), each NHWC or None."""
+              want_act: bool = False, slope: float = 0.2, in_slope: Optional[float] = None,
+              in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """NHWC conv (or transposed conv when ``pw.transposed``) -> (raw, act), each NHWC or None.
+
+    ``in_slope`` (with optional per-(image, channel) ``in_mul``/``in_add``): the conv consumes
+    ``leaky_relu(x*in_mul+in_add, in_slope)`` -- the pre-activation of AttResUNet.py:55 -- applied while x is staged."""
     _dev_check(x, "x")
     n, h, w, c = x.shape
     if c != pw.cin_pad:
@@ -129,15 +133,18 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         oh, ow, epi = h // stride, w // stride, nat.EPI_NHWC
     raw = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_raw else None
     act = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_act else None
-    for t, nm in ((res, "res"), (mul, "mul"), (add, "add")):
+    for t, nm in ((res, "res"), (mul, "mul"), (add, "add"), (in_mul, "in_mul"), (in_add, "in_add")):
         if t is not None:
             _dev_check(t, nm)
+    if in_mul is not None and (tuple(in_mul.shape) != (n, c) or tuple(in_add.shape) != (n, c)):
+        raise ValueError(f"in_mul/in_add must be [{n}, {c}]")
     if res is not None and tuple(res.shape) != (n, oh, ow, pw.cout):
         raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, pw.cout)}")
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
-                     add=nat.ptr(add), y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c,
-                     cout=pw.cout, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks, stride=stride, epi=epi, nchw_op=0,
-                     crop_h=0, crop_w=0, res_sf=1, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
+                     add=nat.ptr(add), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), y_raw=nat.ptr(raw),
+                     y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
+                     stride=stride, epi=epi, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=int(in_slope is not None),
+                     in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
     _launch_conv(d, flops, "conv_mfma")
@@ -160,7 +167,7 @@ def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op:
         if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
             raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0,
-                     y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
+                     in_mul=0, in_add=0, in_act=0, in_slope=0.0, y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
                      nrep=pw.nrep, ks=pw.ks, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
                      res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
     _launch_conv(d, 2.0 * n * h * w * pw.cin_real * pw.cout * pw.ks ** 2, "conv_mfma(nchw)")
