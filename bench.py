@@ -47,26 +47,41 @@ def build_net(device):
     return net, sd
 
 
-def cpu_baseline(sd, size: int, budget_s: float = 20.0):
-    """Time the CPU oracle on all host cores on a bounded sample of the same workload."""
+def cpu_baseline(sd, size: int, budget_s: float = 25.0):
+    """Time the CPU oracle on the host cores on a bounded sample of the same workload.
+
+    torch's CPU convs stop scaling (and then collapse) long before 256 threads on these small batches, so a few thread
+    counts are tried once each and the fastest is used for the timed runs; `cores` reports the threads actually used."""
     from oracle import cpu_ref
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     nimg = 2 if size >= 256 else 8
     x = synth_images(nimg, 3, size, size)
+
+    def run_once():
+        t0 = time.perf_counter()
+        cpu_ref.virnet_denoise(sd, x, **SYN_CFG)
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    best_t, best_n = None, None
     with torch.no_grad():
-        cpu_ref.virnet_denoise(sd, x, **SYN_CFG)            # warm-up (thread pool, oneDNN primitive cache)
-        times = []
-        t_begin = time.perf_counter()
-        while len(times) < 5 and (time.perf_counter() - t_begin < budget_s or not times):
-            t0 = time.perf_counter()
-            cpu_ref.virnet_denoise(sd, x, **SYN_CFG)
-            times.append(time.perf_counter() - t0)
+        for n in sorted({min(avail, k) for k in (8, 16, 32, 64)}):
+            torch.set_num_threads(n)
+            run_once()                                   # warm-up (thread pool, oneDNN primitive cache)
+            t = run_once()
+            if best_t is None or t < best_t:
+                best_t, best_n = t, n
+            if time.perf_counter() - t_begin > budget_s * 0.6:
+                break
+        torch.set_num_threads(best_n)
+        times = [best_t]
+        while len(times) < 5 and time.perf_counter() - t_begin < budget_s:
+            times.append(run_once())
     times.sort()
     med = times[len(times) // 2]
-    return {"value": round(nimg / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/cpu_ref.virnet_denoise on [{nimg},3,{size},{size}] fp32, torch CPU ({cores} threads), "
-                      f"median of {len(times)} runs after 1 warm-up"}
+    return {"value": round(nimg / med, 3), "unit": "images/s", "cores": best_n, "kind": "port",
+            "sample": f"oracle/cpu_ref.virnet_denoise on [{nimg},3,{size},{size}] fp32, torch CPU, {best_n} threads "
+                      f"(fastest of the thread counts tried; {avail} cores available), median of {len(times)} runs"}
 
 
 def load_pmc_traffic():

@@ -64,6 +64,9 @@ def main():
         hbm[k] = {"fetch_bytes_per_launch_corrected": fe.get("FETCH_SIZE", 0) * 1024 * 2 / n,
                   "write_bytes_per_launch": wr.get("WRITE_SIZE", 0) * 1024 / max(1, wr.get("dispatches", 1))}
     res["hbm"] = hbm
+    # drop torch's own tiny kernels from the per-kernel tables (keep ours)
+    for sec in ("kernel_stats", "pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "hbm"):
+        res[sec] = {k: v for k, v in res[sec].items() if not k.startswith(("void at::", "__amd_rocclr"))}
     json.dump(res, sys.stdout, indent=1, sort_keys=True)
 
 
