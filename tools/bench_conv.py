@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="l0,l1,l2")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--mode", default="dual", choices=["dual", "act", "raw"])
+    ap.add_argument("--mode", default="res", choices=["dual", "act", "raw", "res", "pre"])
     args = ap.parse_args()
     torch.manual_seed(0)
     for name in args.shapes.split(","):
@@ -30,8 +30,9 @@ def main():
         cp = ConvParam(c, c, 3).cuda()
         x = torch.rand(n, h, w, c, device="cuda") - 0.5
         res = torch.rand(n, h, w, c, device="cuda") - 0.5
-        kw = dict(res=res, want_raw=True, want_act=True) if args.mode == "dual" else (
-            dict(want_raw=False, want_act=True) if args.mode == "act" else dict(want_raw=True, want_act=False))
+        kw = {"dual": dict(res=res, want_raw=True, want_act=True), "act": dict(want_raw=False, want_act=True),
+              "raw": dict(want_raw=True, want_act=False), "res": dict(res=res, want_raw=True),          # conv2 of a res-block
+              "pre": dict(in_slope=0.2, want_raw=False, want_act=True)}[args.mode]                       # conv1 of a res-block
         pw = cp.packed()
         for _ in range(3):
             ops.conv_mfma(x, pw, **kw)
