@@ -68,7 +68,7 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
 }
 
 template <int KS, int STRIDE, int MREP, int NREP>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const KArgs a) {
+__global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1 : 2)) void conv_mfma_kernel(const KArgs a) {
   constexpr int TH = 4 * MREP;
   constexpr int PAD = KS / 2;
   constexpr int IH = (TH - 1) * STRIDE + KS;
