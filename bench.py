@@ -10,7 +10,7 @@ configs[2]'s 256).  ``--size 128 --batch 64`` runs configs[1].  Scaling is weak:
 collective is the start-up weight broadcast (RCCL), nothing is exchanged per image.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline     : the dominant kernel conv_mfma_kernel<3,1,2,3> (3x3 C->C res-block convs) -- algorithmic FLOPs per launch / its
+  roofline     : the dominant kernel (the 3x3 stride-1 instantiation with the most time: conv_mfma_kernel<3,1,2,3>, the C->C res-block convs) -- algorithmic FLOPs per launch / its
                  average launch duration, measured with HIP events recorded on the launch stream around every launch inside the
                  timed region (rank 0), against the 157.3 TFLOP/s fp32-MFMA peak
   cpu_baseline : the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores on a bounded sample.
@@ -31,18 +31,21 @@ if ROOT not in sys.path:
 
 from virnet_amd import dist as vdist  # noqa: E402
 from virnet_amd import ops  # noqa: E402
-from virnet_amd.networks import VIRAttResUNet  # noqa: E402
+from virnet_amd.networks import VIRAttResUNet, VIRAttResUNetSR  # noqa: E402
 from virnet_amd.utils.synth import synth_images, synth_state_dict  # noqa: E402
 
 # scripts/denoising_virnet_syn.py:62-71
 SYN_CFG = dict(n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input", noise_avg=False)
+# scripts/sisr_virnet_syn.py:53-63 / scripts/testing_demo.py:52-63
+SISR_CFG = dict(n_feat=[96, 160, 224], dep_S=5, dep_K=8, n_resblocks=2, noise_cond=True, kernel_cond=True, extra_mode="Both",
+                noise_avg=True)
+SISR_GFLOP_PER_IMAGE = 180.159         # x4, LR 64x64 -> 256x256 (RNet 178.92, SNet 0.925, KNet 0.311)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
 KFLOP_PER_PIXEL = 4988.736             # conv FLOPs (2*MAC) of the denoise-syn forward per padded pixel
-DOMINANT = (3, 1, 2, 3)                # conv_mfma_kernel<KS=3,STRIDE=1,MREP=2,NREP=3>
 
 
-def build_net(device):
-    net = VIRAttResUNet(im_chn=3, sigma_chn=1, **SYN_CFG)
+def build_net(device, task="denoise"):
+    net = VIRAttResUNet(im_chn=3, sigma_chn=1, **SYN_CFG) if task == "denoise" else VIRAttResUNetSR(im_chn=3, sigma_chn=1, kernel_chn=3, **SISR_CFG)
     sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
     return net, sd
 
@@ -101,10 +104,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256, help="image height=width")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 @256, 64 @128)")
+    ap.add_argument("--task", default="denoise", choices=["denoise", "sisr"],
+                    help="sisr = BASELINE configs[3]: VIRAttResUNetSR x4 on LR 64x64 (-> 256x256), 16 images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
-    batch = args.batch if args.batch is not None else (32 if args.size >= 256 else 64)
+    sisr = args.task == "sisr"
+    if sisr and args.size == 256:
+        args.size = 64                      # LR size; the output is 4x
+    batch = args.batch if args.batch is not None else (16 if sisr else (32 if args.size >= 256 else 64))
 
     rank, local_rank, world = vdist.init()
     if world != args.gpus:
@@ -114,7 +122,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    net, sd = build_net(dev)
+    net, sd = build_net(dev, args.task)
+    fwd = (lambda t: net(t, 4)) if sisr else net
     if rank == 0:
         net.load_state_dict(sd, strict=True)       # other ranks keep their random init until the broadcast
     net = net.to(dev).eval()
@@ -133,14 +142,14 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            net(x)
+            fwd(x)
         timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
         torch.cuda.synchronize()
         barrier()
         ops.set_launch_timer(timer)     # two event records per conv launch, on the launch stream (~us of host time each)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            mu, sigma = net(x)
+            mu = fwd(x)[0]
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -151,16 +160,18 @@ def main():
     roof = None
     if timer is not None:
         summ = timer.summary()
-        d = summ.get(DOMINANT)
+        cands = [k for k in summ if k[0] == 3 and k[1] == 1]
+        dom = max(cands, key=lambda k: summ[k]["ms"]) if cands else None
+        d = summ.get(dom)
         if d:
             avg_ms = d["ms"] / d["launches"]
             achieved = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in summ.values())
-            pmc = load_pmc_traffic()
+            pmc = load_pmc_traffic() if (not sisr and args.size == 256 and batch == 32) else None   # measured on this workload only
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
-                    "kernel": "conv_mfma_kernel<3,1,2,3>", "launches_per_step": d["launches"] // args.steps,
+                    "kernel": "conv_mfma_kernel<%d,%d,%d,%d>" % dom, "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC, algorithmic)", "share_of_conv_time": round(d["ms"] / total_ms, 4),
                     "by_kernel_ms_per_step": {"conv_mfma<%d,%d,%d,%d>" % k: round(v["ms"] / args.steps, 3)
@@ -172,20 +183,22 @@ def main():
         imgs = batch * world * args.steps
         value = imgs / elapsed
         hp = (args.size + 3) // 4 * 4
-        gflop_img = KFLOP_PER_PIXEL * hp * hp / 1e6
+        gflop_img = SISR_GFLOP_PER_IMAGE * (args.size / 64.0) ** 2 if sisr else KFLOP_PER_PIXEL * hp * hp / 1e6
         out = {
-            "metric": "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)",
+            "metric": (f"images/sec (SISR x4 fwd, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if sisr else
+                       "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"VIRAttResUNet denoise-syn forward (n_feat 96/192/288, 3 res-blocks, dep_S 5), {args.size}x{args.size}x3 "
-                                   f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
+            "config": {"workload": (f"VIRAttResUNetSR x4 forward (n_feat 96/160/224, 2 res-blocks, dep_S 5, dep_K 8, extra_mode Both), LR {args.size}x{args.size}x3 "
+                                    if sisr else f"VIRAttResUNet denoise-syn forward (n_feat 96/192/288, 3 res-blocks, dep_S 5), {args.size}x{args.size}x3 ")
+                                   + f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
                        "parallelism": f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), no per-image collective"},
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(sd, args.size),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or sisr) else cpu_baseline(sd, args.size),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,76 @@
+"""Evaluation-harness counterpart (virnet_amd/eval.py) against values produced by the reference's own helpers
+(tests/golden/make_harness_golden.py): the shared-rng iid noise stream and uint8 PSNR.  Plus, on the GPU, the PSNR-parity line
+of BASELINE.json: CBSD68 sigma=50 inputs built exactly as the reference script builds them, HIP path vs CPU oracle <= 0.01 dB."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from virnet_amd import eval as veval
+
+H = json.load(open(os.path.join(GOLDEN, "harness.json")))
+FIX = {n: veval.imread_rgb_uint8(os.path.join(GOLDEN, "cbsd68", n)) for n in H["noise_sigma50"]}
+
+
+def test_psnr_matches_reference_helper():
+    g = np.random.default_rng(H["psnr"]["seed"])
+    a = g.integers(0, 256, size=tuple(H["psnr"]["shape"]), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + g.integers(-9, 10, size=a.shape), 0, 255).astype(np.uint8)
+    assert veval.calculate_psnr(a, b) == pytest.approx(H["psnr"]["border0"], abs=1e-12)
+    assert veval.calculate_psnr(a, b, border=4) == pytest.approx(H["psnr"]["border4"], abs=1e-12)
+    assert veval.calculate_psnr(a, a) == float("inf")
+    with pytest.raises(ValueError):
+        veval.calculate_psnr(a, a[:-1])
+
+
+def test_image_conversions():
+    u = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, 2)
+    f = veval.img_as_float32(u)
+    assert f.dtype == np.float32 and f.max() == 1.0 and np.array_equal(veval.img_as_ubyte(f), u)
+    assert veval.img_as_ubyte(np.array([-0.2, 0.5 / 255, 1.5 / 255, 1.7])).tolist() == [0, 0, 2, 255]   # clip, round half to even
+
+
+def test_sigma50_noise_is_the_scripts_stream():
+    shapes = [tuple(s) for s in H["cbsd68_shapes"]]
+    assert len(shapes) == 68 and H["cbsd68_names"] == sorted(H["cbsd68_names"])
+    images = {v["index"]: FIX[n] for n, v in H["noise_sigma50"].items()}
+    got = veval.noisy_inputs(images, shapes, 50)
+    assert len(got) == len(images)
+    by_index = {v["index"]: v for v in H["noise_sigma50"].values()}
+    for idx, gt, noisy in got:
+        noise = noisy - veval.img_as_float32(gt)
+        ref = by_index[idx]
+        assert noisy.dtype == np.float32 and noisy.min() < 0.0 and noisy.max() > 1.0        # not clipped
+        np.testing.assert_allclose((noisy.astype(np.float64) - veval.img_as_float32(gt)).reshape(-1)[:8], ref["first8"], atol=2e-7)
+        assert abs(float(noise.astype(np.float64).sum()) - ref["sum"]) < 0.5
+
+
+@pytest.mark.gpu
+def test_psnr_parity_cbsd68_sigma50(manifest):
+    """BASELINE.json: 'PSNR within 0.01 dB on CBSD68' -- three CBSD68 images (481x321 / 321x481: reflect pad + crop), sigma=50
+    noise from the replayed stream, denoise-syn network on identical synthetic weights: HIP path vs CPU oracle."""
+    from oracle import cpu_ref
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_state_dict
+    cfg = dict(manifest["configs"]["syn"]); cfg.pop("kind")
+    net = VIRAttResUNet(**cfg)
+    sd = synth_state_dict({k: tuple(s) for k, s in manifest["shapes"]["syn"].items()})
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()                                 # NB the script never calls .eval() (no BN/dropout): same numerics
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+    shapes = [tuple(s) for s in H["cbsd68_shapes"]]
+    images = {v["index"]: FIX[n] for n, v in H["noise_sigma50"].items()}
+    for idx, gt, noisy in veval.noisy_inputs(images, shapes, 50):
+        x = torch.from_numpy(noisy.transpose(2, 0, 1)[np.newaxis].copy())
+        with torch.no_grad():
+            mu, _ = net(x.cuda())
+            mu_ref, _ = cpu_ref.virnet_denoise(sd, x, **kw)
+        den = veval.img_as_ubyte(mu.squeeze(0).cpu().numpy().transpose(1, 2, 0))
+        den_ref = veval.img_as_ubyte(mu_ref.squeeze(0).numpy().transpose(1, 2, 0))
+        p, p_ref = veval.calculate_psnr(den, gt), veval.calculate_psnr(den_ref, gt)
+        assert abs(p - p_ref) <= 0.01, (idx, p, p_ref)
+        assert float((mu.cpu() - mu_ref).abs().max()) <= 1e-3
+        assert int(np.abs(den.astype(int) - den_ref.astype(int)).max()) <= 1      # identical up to rounding ties
