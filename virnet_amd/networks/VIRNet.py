@@ -15,6 +15,7 @@ from .AttResUNet import AttResUNet
 from .DnCNN import DnCNN
 from .KNet import KernelNet as KNet
 from .. import engine
+from ..graph import GraphedForward
 
 log_max = log(1e2)    # VIRNet.py:15
 log_min = log(1e-10)  # VIRNet.py:16
@@ -36,6 +37,10 @@ class VIRAttResUNet(nn.Module):
         """x [N,C,H,W] -> (mu [N,C,H,W], sigma [N,sigma_chn,H,W]); sigma is a variance map (VIRNet.py:42-46)."""
         return engine.denoise_forward(self, x)
 
+    def graphed(self) -> GraphedForward:
+        """hipGraph-replayed forward for the one-image-per-call script path; outputs are reused buffers (see GraphedForward)."""
+        return GraphedForward(lambda x: engine.denoise_forward(self, x))
+
 
 class VIRAttResUNetSR(nn.Module):
     """Super-resolution: SNet + KNet (kernel descriptor) + RNet on the nearest-upsampled image.  Reference: VIRNet.py:48-97."""
@@ -54,3 +59,7 @@ class VIRAttResUNetSR(nn.Module):
     def forward(self, x: torch.Tensor, sf: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """x [N,C,h,w], sf -> (mu [N,C,h*sf,w*sf], kinfo [N,kernel_chn], sigma) (VIRNet.py:80-97)."""
         return engine.sisr_forward(self, x, sf)
+
+    def graphed(self) -> GraphedForward:
+        """hipGraph-replayed forward: `g = net.graphed(); mu, kinfo, sigma = g(x, sf)`."""
+        return GraphedForward(lambda x, sf: engine.sisr_forward(self, x, sf))
