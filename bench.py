@@ -174,8 +174,8 @@ def main():
                     "kernel": "conv_mfma_kernel<%d,%d,%d,%d>" % dom, "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC, algorithmic)", "share_of_conv_time": round(d["ms"] / total_ms, 4),
-                    "by_kernel_ms_per_step": {"conv_mfma<%d,%d,%d,%d>" % k: round(v["ms"] / args.steps, 3)
-                                              for k, v in sorted(summ.items())}}
+                    "by_kernel_ms_per_step": {("conv3x3_thin<cout=%d>" % k[3] if k[0] == "thin" else "conv_mfma<%d,%d,%d,%d>" % k):
+                                              round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))}}
     if world > 1:
         torch.distributed.barrier()
 

@@ -101,6 +101,27 @@ int virnet_conv_mfma(const virnet_conv_desc* d, void* stream);
 int virnet_conv_mfma_variant(const virnet_conv_desc* d, int out[4]);
 
 /* ------------------------------------------------------------------------------------------------
+ * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):
+ * AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173), DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43),
+ * KernelNet.tail conv (KNet.py:49).  Weights: virnet_pack_thin_weight of the OIHW tensor.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct virnet_thin_desc {
+  const float* x;      /* NHWC [n][h][w][c], c a multiple of 16 */
+  const float* wpack;  /* [c/16][9][16][4] from virnet_pack_thin_weight */
+  const float* bias;   /* [cout] or NULL */
+  const float* res;    /* VIRNET_NCHW_ADD: NCHW [n][cout][crop_h/res_sf][crop_w/res_sf] */
+  float* y;            /* NCHW [n][cout][crop_h][crop_w] */
+  int n, h, w, c, cout;
+  int crop_h, crop_w;  /* stored extent (<= h, w) */
+  int op;              /* VIRNET_NCHW_* */
+  int res_sf;          /* nearest up-sampling factor of res (0/1 = none) */
+  float clamp_lo, clamp_hi;
+} virnet_thin_desc;
+size_t virnet_thin_weight_floats(int c_pad);
+int virnet_pack_thin_weight(const float* w_oihw, int cout, int c, int c_pad, float* packed, void* stream);
+int virnet_conv3x3_thin(const virnet_thin_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Image entry: NCHW -> 16-channel NHWC pixel records, fusing
  *   - the nearest x`sf` up-sampling of VIRNet.py:83 (sf = 1 for denoising),
  *   - the bottom/right reflect pad of utils/util_net.py:20-25 (hp >= h*sf, wp >= w*sf),

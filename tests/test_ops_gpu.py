@@ -158,6 +158,28 @@ def test_thin_output_epilogues():
     assert maxerr(outp.cpu(), v) <= 1e-4   # |v| reaches ~40 here
 
 
+@pytest.mark.parametrize("c,cout,h,w,n", [(96, 3, 12, 36, 2), (64, 1, 9, 40, 1), (64, 3, 17, 33, 2), (160, 4, 8, 70, 1)])
+def test_thin_conv_kernel(c, cout, h, w, n):
+    """Bandwidth-bound few-channel conv (tail / SNet last / KNet tail): plain, crop + residual (also through nearest x2), exp(clamp)."""
+    cp = make_conv(c, cout)
+    x = rnd(n, c, h, w, seed=50)
+    v = F.conv2d(x, cp.weight.detach(), cp.bias.detach(), padding=1)
+    cp.cuda()
+    pw = cp.packed_thin()
+    assert maxerr(ops.conv3x3_thin(nhwc(x), pw, (h, w)).cpu(), v) <= TOL
+    ch, cw = h - 2, w - 3
+    xin = rnd(n, cout, ch, cw, seed=51)
+    assert maxerr(ops.conv3x3_thin(nhwc(x), pw, (ch, cw), op=nat.NCHW_ADD, res=xin.cuda()).cpu(), v[..., :ch, :cw] + xin) <= TOL
+    if h % 2 == 0 and w % 2 == 0:
+        xlr = rnd(n, cout, h // 2, w // 2, seed=52)
+        ref = v + F.interpolate(xlr, scale_factor=2, mode="nearest")
+        assert maxerr(ops.conv3x3_thin(nhwc(x), pw, (h, w), op=nat.NCHW_ADD, res=xlr.cuda(), res_sf=2).cpu(), ref) <= TOL
+    ref = torch.exp(torch.clamp(v, min=-0.5, max=0.7))
+    assert maxerr(ops.conv3x3_thin(nhwc(x), pw, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(-0.5, 0.7)).cpu(), ref) <= TOL
+    with pytest.raises(ValueError, match="1..4 output channels"):
+        ops.pack_thin_weight(torch.zeros(5, 16, 3, 3, device="cuda"), None)
+
+
 def test_pack_input_reflect_upsample_concat():
     """Entry kernel vs pad_input / interpolate / cat (util_net.py:20-25, VIRNet.py:83-95, AttResUNet.py:153)."""
     x, sig = rnd(2, 3, 37, 45, seed=16, lo=0, hi=1), rnd(2, 1, 37, 45, seed=17, lo=0.1, hi=2)

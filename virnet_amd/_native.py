@@ -46,6 +46,15 @@ class PackDesc(C.Structure):
     ]
 
 
+class ThinDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wpack", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("y", C.c_void_p),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("cout", C.c_int),
+        ("crop_h", C.c_int), ("crop_w", C.c_int), ("op", C.c_int), ("res_sf", C.c_int),
+        ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+    ]
+
+
 class SftWeights(C.Structure):
     _fields_ = [
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
@@ -70,6 +79,9 @@ SYMBOLS = [
     ("virnet_conv_mfma", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("virnet_conv_mfma_variant", C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int * 4)]),
     ("virnet_pack_input", C.c_int, [C.POINTER(PackDesc), C.c_void_p]),
+    ("virnet_thin_weight_floats", C.c_size_t, [C.c_int]),
+    ("virnet_pack_thin_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("virnet_conv3x3_thin", C.c_int, [C.POINTER(ThinDesc), C.c_void_p]),
     ("virnet_conv_head_s4", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
     ("virnet_gap_nchw", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

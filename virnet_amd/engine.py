@@ -43,6 +43,13 @@ def _ceil_to(v: int, m: int) -> int:
     return (v + m - 1) // m * m
 
 
+def _conv_planar(x: Tensor, conv, crop_hw, **kw) -> Tensor:
+    """3x3 conv with planar (NCHW) store: the bandwidth-bound kernel for <= 4 output channels, the MFMA kernel otherwise."""
+    if conv.cout <= 4:
+        return ops.conv3x3_thin(x, conv.packed_thin(), crop_hw, **kw)
+    return ops.conv_mfma_nchw(x, conv.packed(), crop_hw, **kw)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # SNet (reference networks/DnCNN.py:37-44)
 # ----------------------------------------------------------------------------------------------------------------
@@ -54,14 +61,14 @@ def snet_forward(snet, x: Tensor, mode: str = "raw") -> Tensor:
     _, cur = ops.conv_mfma(rec, snet.conv1.packed(), want_raw=False, want_act=True, slope=0.25)
     for key in sorted(snet.mid_layer.keys(), key=int):
         _, cur = ops.conv_mfma(cur, snet.mid_layer[key].packed(), want_raw=False, want_act=True, slope=0.25)
-    last = snet.conv_last.packed()
+    last = snet.conv_last
     if snet.noise_avg:
-        raw = ops.conv_mfma_nchw(cur, last, (h, w))
+        raw = _conv_planar(cur, last, (h, w))
         fin = ops.GAP_EXPCLAMP if mode == "sigma" else ops.GAP_MEAN
         return ops.gap_nchw(raw, fin, (LOG_MIN, LOG_MAX)).view(n, -1, 1, 1)
     if mode == "sigma":
-        return ops.conv_mfma_nchw(cur, last, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(LOG_MIN, LOG_MAX))
-    return ops.conv_mfma_nchw(cur, last, (h, w))
+        return _conv_planar(cur, last, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(LOG_MIN, LOG_MAX))
+    return _conv_planar(cur, last, (h, w))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -78,7 +85,7 @@ def knet_forward(knet, x: Tensor) -> Tensor:
         gate = ops.ca_gate(hcv, ca["0"].weight, ca["0"].bias, ca["2"].weight, ca["2"].bias)          # KNet.py:15-25
         cur = ops.scale_add(hcv, gate, cur)                                                           # KNet.py:26,38
     oh, ow = cur.shape[1:3]
-    raw = ops.conv_mfma_nchw(cur, knet.tail["0"].packed(), (oh, ow))                                  # KNet.py:49
+    raw = _conv_planar(cur, knet.tail["0"], (oh, ow))                                                 # KNet.py:49
     return ops.gap_nchw(raw, ops.GAP_KINFO, (K_LOG_MIN, LOG_MAX)).view(n, -1, 1, 1)                  # KNet.py:50,56-59
 
 
@@ -155,7 +162,7 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
         x, _ = ops.conv_mfma(x, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True)   # AttResUNet.py:84-87
         for blk in up.body:
             x = _res_block(x, blk, None, 0)
-    return ops.conv_mfma_nchw(x, rnet.tail.packed(), (H, W), op=nat.NCHW_ADD, res=x_in, res_sf=sf)   # AttResUNet.py:173
+    return _conv_planar(x, rnet.tail, (H, W), op=nat.NCHW_ADD, res=x_in, res_sf=sf)                  # AttResUNet.py:173
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -45,6 +45,15 @@ class ConvParam(nn.Module):
             self._pack_key = key
         return self._pack
 
+    def packed_thin(self) -> ops.PackedWeight:
+        """Packing for the bandwidth-bound few-output-channel kernel (3x3, cout <= 4), cached like ``packed``."""
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        if getattr(self, "_thin", None) is None or self._thin_key != key:
+            self._thin = ops.pack_thin_weight(self.weight, self.bias)
+            self._thin_key = key
+        return self._thin
+
     def forward(self, *args, **kwargs):  # pragma: no cover - guard
         raise RuntimeError("ConvParam holds parameters only; the convolution runs inside libvirnet_hip "
                            "(call the enclosing network's forward)")

@@ -174,6 +174,51 @@ def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op:
     return out
 
 
+def pack_thin_weight(weight: Tensor, bias: Optional[Tensor]) -> PackedWeight:
+    """Pack an OIHW 3x3 weight with 1..4 output channels for virnet_conv3x3_thin."""
+    lib = nat.load()
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or not 1 <= cout <= 4:
+        raise ValueError(f"thin conv handles 3x3 kernels with 1..4 output channels, got {tuple(weight.shape)}")
+    c_pad = (cin + 15) // 16 * 16
+    out = torch.empty(lib.virnet_thin_weight_floats(c_pad), dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_thin_weight(nat.ptr(weight), cout, cin, c_pad, nat.ptr(out), nat.stream_handle()), "pack_thin_weight")
+    b = None
+    if bias is not None:
+        b = bias.detach()
+        _dev_check(b, "bias")
+    return PackedWeight(out, b, 3, cout, cin, c_pad, 4, 0, False)
+
+
+def conv3x3_thin(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: int = nat.NCHW_PLAIN,
+                 res: Optional[Tensor] = None, res_sf: int = 1, clamp: Tuple[float, float] = (0.0, 0.0)) -> Tensor:
+    """3x3 conv to 1..4 channels, planar (NCHW) store with crop and fused `+res` / `exp(clamp(.))` (bandwidth-bound kernel)."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    if c != pw.cin_pad or pw.nrep != 0:
+        raise ValueError(f"x has {c} channels / weight is not a thin pack (expects {pw.cin_pad})")
+    ch, cw = crop_hw
+    out = torch.empty((n, pw.cout, ch, cw), dtype=torch.float32, device=x.device)
+    if res is not None:
+        _dev_check(res, "res")
+        if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
+            raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
+    d = nat.ThinDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), y=nat.ptr(out), n=n, h=h, w=w,
+                     c=c, cout=pw.cout, crop_h=ch, crop_w=cw, op=op, res_sf=res_sf, clamp_lo=clamp[0], clamp_hi=clamp[1])
+    lib = nat.load()
+    if _TIMER is None:
+        nat.check(lib.virnet_conv3x3_thin(C.byref(d), nat.stream_handle()), "conv3x3_thin")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.check(lib.virnet_conv3x3_thin(C.byref(d), nat.stream_handle()), "conv3x3_thin")
+        e1.record()
+        _TIMER.records.append((("thin", 3, 1, pw.cout), 2.0 * n * h * w * pw.cin_real * pw.cout * 9, e0, e1))
+    return out
+
+
 def pack_input(x: Tensor, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor] = None,
                map_: Optional[Tensor] = None, map_sf: int = 1, map_sqrt: bool = False) -> Tensor:
     """NCHW image (+ per-image vector / per-pixel map) -> [N, hp, wp, 16] NHWC records (up-sample, reflect pad, concat)."""
