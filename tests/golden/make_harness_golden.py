@@ -48,6 +48,15 @@ a = g.integers(0, 256, size=(37, 41, 3), dtype=np.uint8)
 b = np.clip(a.astype(np.int32) + g.integers(-9, 10, size=a.shape), 0, 255).astype(np.uint8)
 psnr = dict(seed=7, shape=[37, 41, 3], border0=util_image.calculate_psnr(a, b, border=0, ycbcr=False),
             border4=util_image.calculate_psnr(a, b, border=4, ycbcr=False))
-json.dump(dict(cbsd68_names=names, cbsd68_shapes=shapes, noise_sigma50=noise_head, psnr=psnr),
+# niid variance maps (utils/util_denoising.py:69-124) and the Y conversion (utils/util_image.py:129-153)
+rng2 = util_denoising.noise_generator()
+maps = [util_denoising.peaks(256), util_denoising.sincos_kernel(), util_denoising.generate_gauss_kernel_mix(256, 256, rng2)]
+after = rng2.standard_normal(size=4).tolist()          # the stream position after the mixture map consumed its draws
+niid = dict(stats=[dict(min=float(m.min()), max=float(m.max()), sum=float(np.asarray(m, dtype=np.float64).sum()),
+                        probe=[float(m[17, 200]), float(m[255, 0]), float(m[128, 64])]) for m in maps], next_normals=after)
+ycase = util_image.rgb2ycbcr(a, True)
+ychk = dict(sum=int(ycase.astype(np.int64).sum()), first=ycase.reshape(-1)[:6].tolist(),
+            psnr_y=util_image.calculate_psnr(a, b, border=4, ycbcr=True))
+json.dump(dict(niid=niid, ycbcr=ychk, cbsd68_names=names, cbsd68_shapes=shapes, noise_sigma50=noise_head, psnr=psnr),
           open(os.path.join(HERE, "harness.json"), "w"), indent=1)
 print("fixtures", want, "psnr", psnr)

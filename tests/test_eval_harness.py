@@ -48,6 +48,35 @@ def test_sigma50_noise_is_the_scripts_stream():
         assert abs(float(noise.astype(np.float64).sum()) - ref["sum"]) < 0.5
 
 
+def test_niid_maps_match_reference_helpers():
+    rng = np.random.default_rng(veval.NOISE_SEED)
+    maps = [veval.peaks(256), veval.sincos_kernel(), veval.gauss_kernel_mix(256, 256, rng)]
+    for m, ref in zip(maps, H["niid"]["stats"]):
+        assert m.shape == (256, 256)
+        assert float(m.min()) == pytest.approx(ref["min"], rel=1e-6, abs=1e-12) and float(m.max()) == pytest.approx(ref["max"], rel=1e-6)
+        assert float(np.asarray(m, dtype=np.float64).sum()) == pytest.approx(ref["sum"], rel=1e-6)
+        np.testing.assert_allclose([m[17, 200], m[255, 0], m[128, 64]], ref["probe"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(rng.standard_normal(size=4), H["niid"]["next_normals"], rtol=0, atol=0)   # same stream position
+    sig = veval.niid_sigma_maps(np.random.default_rng(veval.NOISE_SEED))
+    assert all(abs(s.min() - 10 / 255) < 1e-9 and abs(s.max() - 75 / 255) < 1e-9 for s in sig)
+    r = veval.resize_nearest_exact(np.arange(12.0).reshape(3, 4), 6, 6)
+    assert r.shape == (6, 6) and r[0, 0] == 0 and r[5, 5] == 11 and r[2, 3] == 4 * 1 + 2
+
+
+def test_y_channel_and_ssim():
+    g = np.random.default_rng(H["psnr"]["seed"])
+    a = g.integers(0, 256, size=tuple(H["psnr"]["shape"]), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + g.integers(-9, 10, size=a.shape), 0, 255).astype(np.uint8)
+    y = veval.rgb2y_uint8(a)
+    assert int(y.astype(np.int64).sum()) == H["ycbcr"]["sum"] and y.reshape(-1)[:6].tolist() == H["ycbcr"]["first"]
+    assert veval.calculate_psnr_y(a, b, border=4) == pytest.approx(H["ycbcr"]["psnr_y"], abs=1e-12)
+    # SSIM is restated from its definition (the reference's needs cv2): definitional properties only
+    assert veval.calculate_ssim(a, a) == pytest.approx(1.0, abs=1e-12)
+    s_ab, s_ac = veval.calculate_ssim(a, b), veval.calculate_ssim(a, 255 - a)
+    assert 0.5 < s_ab < 1.0 and s_ac < s_ab and veval.calculate_ssim(a, b) == veval.calculate_ssim(b, a)
+    assert veval.calculate_ssim(a, b, border=3, ycbcr=True) <= 1.0
+
+
 @pytest.mark.gpu
 def test_psnr_parity_cbsd68_sigma50(manifest):
     """BASELINE.json: 'PSNR within 0.01 dB on CBSD68' -- three CBSD68 images (481x321 / 321x481: reflect pad + crop), sigma=50

@@ -384,8 +384,8 @@ int pick_nrep(int nblocks32) {
 int pick_mrep(const virnet_conv_desc* d) {
   if (d->stride == 2 || d->nrep >= 4) return 1;   // MREP=2 with >= 4 channel blocks would spill (256-VGPR budget)
   static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();  // tuning knob
-  if (forced == 1 || forced == 2) return forced;
   const int oh = d->h, ow = d->w;
+  if (forced == 1 || forced == 2 || (forced == 3 && d->ks == 3 && d->nrep == 2)) return forced;
   const long wg8 = (long)d->n * ((oh + 7) / 8) * ((ow + 31) / 32) * (d->n_pad / (32 * d->nrep));
   return wg8 < 2048 ? 1 : 2;
 }
@@ -458,36 +458,17 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
       return virnet::set_error("virnet_conv_mfma: unknown epilogue %d", d->epi);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool small = pick_mrep(d) == 1;
-#define VIRNET_CASE(KS_, S_, M_, N_) return launch<KS_, S_, M_, N_>(k, st)
-  if (d->ks == 3 && d->stride == 1) {
-    switch (d->nrep) {
-      case 1: if (small) VIRNET_CASE(3, 1, 1, 1); else VIRNET_CASE(3, 1, 2, 1);
-      case 2: if (small) VIRNET_CASE(3, 1, 1, 2); else VIRNET_CASE(3, 1, 2, 2);
-      case 3: if (small) VIRNET_CASE(3, 1, 1, 3); else VIRNET_CASE(3, 1, 2, 3);
-      case 4: VIRNET_CASE(3, 1, 1, 4);
-      case 5: VIRNET_CASE(3, 1, 1, 5);
-      case 7: VIRNET_CASE(3, 1, 1, 7);
-    }
-  } else if (d->ks == 3 && d->stride == 2) {
-    switch (d->nrep) {
-      case 1: VIRNET_CASE(3, 2, 1, 1);
-      case 2: VIRNET_CASE(3, 2, 1, 2);
-      case 3: VIRNET_CASE(3, 2, 1, 3);
-      case 4: VIRNET_CASE(3, 2, 1, 4);
-      case 5: VIRNET_CASE(3, 2, 1, 5);
-      case 7: VIRNET_CASE(3, 2, 1, 7);
-    }
-  } else if (d->ks == 1 && d->stride == 1) {
-    switch (d->nrep) {
-      case 1: if (small) VIRNET_CASE(1, 1, 1, 1); else VIRNET_CASE(1, 1, 2, 1);
-      case 2: if (small) VIRNET_CASE(1, 1, 1, 2); else VIRNET_CASE(1, 1, 2, 2);
-      case 3: if (small) VIRNET_CASE(1, 1, 1, 3); else VIRNET_CASE(1, 1, 2, 3);
-      case 4: VIRNET_CASE(1, 1, 1, 4);
-      case 5: VIRNET_CASE(1, 1, 1, 5);
-      case 7: VIRNET_CASE(1, 1, 1, 7);
-    }
-  }
+  const int mrep = pick_mrep(d);
+#define VIRNET_CASE(KS_, S_, M_, N_) \
+  if (d->ks == KS_ && d->stride == S_ && mrep == M_ && d->nrep == N_) return launch<KS_, S_, M_, N_>(k, st)
+  VIRNET_CASE(3, 1, 1, 1); VIRNET_CASE(3, 1, 2, 1);
+  VIRNET_CASE(3, 1, 1, 2); VIRNET_CASE(3, 1, 2, 2); VIRNET_CASE(3, 1, 3, 2);
+  VIRNET_CASE(3, 1, 1, 3); VIRNET_CASE(3, 1, 2, 3);
+  VIRNET_CASE(3, 1, 1, 4); VIRNET_CASE(3, 1, 1, 5); VIRNET_CASE(3, 1, 1, 7);
+  VIRNET_CASE(3, 2, 1, 1); VIRNET_CASE(3, 2, 1, 2); VIRNET_CASE(3, 2, 1, 3); VIRNET_CASE(3, 2, 1, 4); VIRNET_CASE(3, 2, 1, 5);
+  VIRNET_CASE(3, 2, 1, 7);
+  VIRNET_CASE(1, 1, 1, 1); VIRNET_CASE(1, 1, 2, 1); VIRNET_CASE(1, 1, 1, 2); VIRNET_CASE(1, 1, 2, 2); VIRNET_CASE(1, 1, 1, 3);
+  VIRNET_CASE(1, 1, 2, 3); VIRNET_CASE(1, 1, 1, 4); VIRNET_CASE(1, 1, 1, 5); VIRNET_CASE(1, 1, 1, 7);
 #undef VIRNET_CASE
-  return virnet::set_error("virnet_conv_mfma: no kernel for ks=%d stride=%d nrep=%d", d->ks, d->stride, d->nrep);
+  return virnet::set_error("virnet_conv_mfma: no kernel for ks=%d stride=%d mrep=%d nrep=%d", d->ks, d->stride, mrep, d->nrep);
 }

@@ -69,3 +69,102 @@ def noisy_inputs(images: dict, shapes: Sequence[Tuple[int, int]], sigma: int) ->
         if s > sigma:
             break
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# niid cases (scripts/denoising_virnet_syn.py:98-102,118-127): three variance maps rescaled to [10,75]/255 and resized to the image
+# ---------------------------------------------------------------------------------------------------------------------
+SIGMA_MIN, SIGMA_MAX = 10 / 255.0, 75 / 255.0      # scripts/denoising_virnet_syn.py:97-98
+
+
+def peaks(n: int) -> np.ndarray:
+    """MATLAB's peaks surface on [-3,3]^2 (utils/util_denoising.py:69-78)."""
+    x = np.linspace(-3, 3, n)
+    xx, yy = np.meshgrid(x, x)
+    return (3 * (1 - xx) ** 2 * np.exp(-xx ** 2 - (yy + 1) ** 2) - 10 * (xx / 5.0 - xx ** 3 - yy ** 5) * np.exp(-xx ** 2 - yy ** 2)
+            - 1 / 3.0 * np.exp(-(xx + 1) ** 2 - yy ** 2))
+
+
+def sincos_kernel() -> np.ndarray:
+    """sin(x)+cos(y) on [1,10]x[1,20], 256x256 (utils/util_denoising.py:120-124)."""
+    xx, yy = np.meshgrid(np.linspace(1, 10, 256), np.linspace(1, 20, 256))
+    return np.sin(xx) + np.cos(yy)
+
+
+def gauss_kernel_mix(h: int, w: int, rng: np.random.Generator) -> np.ndarray:
+    """Mixture of one Gaussian bump per 32x32 patch (utils/util_denoising.py:80-118); draw order: x-centres, y-centres, scales."""
+    pch = 32
+    kh, kw = h // pch, w // pch
+    k = kh * kw
+    cw = (rng.uniform(low=0, high=pch, size=(kh, kw)) + (np.arange(kw) * pch).reshape(1, -1)).reshape(1, 1, k).astype(np.float32)
+    chh = (rng.uniform(low=0, high=pch, size=(kh, kw)) + (np.arange(kh) * pch).reshape(-1, 1)).reshape(1, 1, k).astype(np.float32)
+    scale = rng.uniform(low=pch / 2, high=pch, size=(1, 1, k)).astype(np.float32)
+    xx, yy = np.meshgrid(np.arange(0, w), np.arange(0, h))
+    xx, yy = xx[:, :, None].astype(np.float32), yy[:, :, None].astype(np.float32)
+    zz = 1.0 / (2 * np.pi * scale ** 2) * np.exp((-(xx - cw) ** 2 - (yy - chh) ** 2) / (2 * scale ** 2))
+    return zz.sum(axis=2) / k
+
+
+def resize_nearest_exact(a: np.ndarray, h: int, w: int) -> np.ndarray:
+    """cv2.resize(..., INTER_NEAREST_EXACT): source index floor((dst + 0.5) * in/out)  (restated from its definition; cv2 is not
+    available in the build container, so this one is not pinned against the reference)."""
+    ih, iw = a.shape[:2]
+    ys = np.minimum(np.floor((np.arange(h) + 0.5) * (ih / h)).astype(np.int64), ih - 1)
+    xs = np.minimum(np.floor((np.arange(w) + 0.5) * (iw / w)).astype(np.int64), iw - 1)
+    return a[ys][:, xs]
+
+
+def niid_sigma_maps(rng: np.random.Generator) -> List[np.ndarray]:
+    """The three 256x256 sigma maps of the niid cases, rescaled to [10/255, 75/255] (scripts/denoising_virnet_syn.py:99-102,118).
+    `rng` must be the fresh evaluation generator: the mixture map consumes its first draws."""
+    maps = [peaks(256), sincos_kernel(), gauss_kernel_mix(256, 256, rng)]
+    return [SIGMA_MIN + (m - m.min()) / (m.max() - m.min()) * (SIGMA_MAX - SIGMA_MIN) for m in maps]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Y channel and SSIM (utils/util_image.py:17-66,129-153)
+# ---------------------------------------------------------------------------------------------------------------------
+def rgb2y_uint8(im: np.ndarray) -> np.ndarray:
+    """MATLAB-style luma of a uint8 RGB image, rounded back to uint8 (utils/util_image.py:129-153 with only_y=True)."""
+    y = np.dot(im.astype(np.float64), np.array([65.481, 128.553, 24.966]) / 255.0) + 16.0
+    return y.round().astype(np.uint8)
+
+
+def _gauss_window(size: int = 11, sigma: float = 1.5) -> np.ndarray:
+    g = np.exp(-((np.arange(size) - (size - 1) / 2.0) ** 2) / (2 * sigma ** 2))
+    g /= g.sum()                                   # cv2.getGaussianKernel(11, 1.5)
+    return np.outer(g, g)
+
+
+def _filter_valid(a: np.ndarray, win: np.ndarray) -> np.ndarray:
+    from numpy.lib.stride_tricks import sliding_window_view
+    return np.einsum("ijkl,kl->ij", sliding_window_view(a, win.shape), win)   # == cv2.filter2D(...)[5:-5, 5:-5]
+
+
+def ssim_channel(a: np.ndarray, b: np.ndarray) -> float:
+    """SSIM of two single-channel [0,255] images: 11x11 Gaussian (sigma 1.5), valid region only (utils/util_image.py:17-37)."""
+    c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    a, b, win = a.astype(np.float64), b.astype(np.float64), _gauss_window()
+    mu1, mu2 = _filter_valid(a, win), _filter_valid(b, win)
+    s1 = _filter_valid(a * a, win) - mu1 ** 2
+    s2 = _filter_valid(b * b, win) - mu2 ** 2
+    s12 = _filter_valid(a * b, win) - mu1 * mu2
+    return float((((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 ** 2 + mu2 ** 2 + c1) * (s1 + s2 + c2))).mean())
+
+
+def calculate_ssim(im1: np.ndarray, im2: np.ndarray, border: int = 0, ycbcr: bool = False) -> float:
+    """Mean SSIM over the RGB channels, or on Y (utils/util_image.py:39-66)."""
+    if im1.shape != im2.shape:
+        raise ValueError("Input images must have the same dimensions.")
+    if ycbcr:
+        im1, im2 = rgb2y_uint8(im1), rgb2y_uint8(im2)
+    h, w = im1.shape[:2]
+    im1, im2 = im1[border:h - border, border:w - border], im2[border:h - border, border:w - border]
+    if im1.ndim == 2:
+        return ssim_channel(im1, im2)
+    return float(np.mean([ssim_channel(im1[:, :, i], im2[:, :, i]) for i in range(im1.shape[2])]))
+
+
+def calculate_psnr_y(im1: np.ndarray, im2: np.ndarray, border: int = 0) -> float:
+    """PSNR on the Y channel (utils/util_image.py:68-89 with ycbcr=True; the SISR scripts use border = sf**2)."""
+    return calculate_psnr(rgb2y_uint8(im1), rgb2y_uint8(im2), border)
