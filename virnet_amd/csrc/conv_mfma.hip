@@ -63,8 +63,10 @@ struct KArgs {
 };
 
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
+// LeakyReLU for slopes in [0, 1] (the reference uses 0.2 / 0.25): max(u, s*u) -- one multiply + one max, no compare/select.
 __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
-  return f32x4{u.x > 0.f ? u.x : u.x * s, u.y > 0.f ? u.y : u.y * s, u.z > 0.f ? u.z : u.z * s, u.w > 0.f ? u.w : u.w * s};
+  const f32x4 t = u * s;
+  return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
 }
 
 template <int KS, int STRIDE, int MREP, int NREP>
@@ -134,11 +136,11 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   const bool in_sft = a.in_mul != nullptr;
   const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + 4 * (tid & 3) : nullptr;
   const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + 4 * (tid & 3) : nullptr;
+  // Branch-free for every mode: without SFT m4 = 1, a4 = 0 (v*1+0 == v exactly); without activation the slope is 1
+  // (max(v, v) == v).  ~12 VALU ops per staged piece in the tail of a tap.
+  const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
   auto stage_x = [&](f32x4 v, bool inb, const f32x4& m4, const f32x4& a4) -> f32x4 {
-    if (a.in_act) {
-      if (in_sft) v = v * m4 + a4;
-      v = lrelu4(v, a.in_slope);
-    }
+    v = lrelu4(v * m4 + a4, in_slope_eff);
     return inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   // weight stage `stage` -> registers (linear 16-B pieces; the packed global image IS the LDS image)
@@ -419,6 +421,8 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
                  d->n_pad, d->nrep);
   VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_mfma: in_mul and in_add must be given together");
   VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_mfma: in_mul/in_add without in_act");
+  VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_mfma: in_slope=%g outside [0,1]", d->in_slope);
+  VIRNET_REQUIRE(!d->y_act || (d->slope >= 0.f && d->slope <= 1.f), "virnet_conv_mfma: slope=%g outside [0,1]", d->slope);
   KArgs k{};
   k.x = d->x; k.wp = d->wpack; k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
   k.in_mul = d->in_mul; k.in_add = d->in_add; k.in_act = d->in_act; k.in_slope = d->in_slope;
