@@ -97,12 +97,13 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   const int ncb = a.NP / NB;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
-  const int cb = q % ncb;
-  const int tile = xcd * a.tiles_per_xcd + q / ncb;
+  // (integer division runs on the VALU: pin the wave-uniform results back into SGPRs so every derived pointer stays scalar)
+  const int cb = __builtin_amdgcn_readfirstlane(q % ncb);
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + q / ncb);
   if (q / ncb >= a.tiles_per_xcd || tile >= a.ntiles) return;
-  const int tx = tile % a.ntx;
-  const int ty = (tile / a.ntx) % a.nty;
-  const int img = tile / (a.ntx * a.nty);
+  const int tx = __builtin_amdgcn_readfirstlane(tile % a.ntx);
+  const int ty = __builtin_amdgcn_readfirstlane((tile / a.ntx) % a.nty);
+  const int img = __builtin_amdgcn_readfirstlane(tile / (a.ntx * a.nty));
   const int oy0 = ty * TH, ox0 = tx * 32;
   const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
 
