@@ -292,10 +292,16 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
     for (int mr = 0; mr < MREP; ++mr) {
       const int oy = oy0 + wave * MREP + mr;
       ok[mr] = oy < a.OH && px < a.OW;
-      eo[mr] = convt ? (unsigned)((2 * oy) * OWs + 2 * px) * (unsigned)C : (unsigned)(oy * OWs + px) * (unsigned)C;
+      const int oyc = min(oy, a.OH - 1), pxc = min(px, a.OW - 1);      // clamped: loads are always issued, stores predicated
+      eo[mr] = convt ? (unsigned)((2 * oyc) * OWs + 2 * pxc) * (unsigned)C : (unsigned)(oyc * OWs + pxc) * (unsigned)C;
     }
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
+      // per 32-channel slab: issue the 4 bias quads and all 4*MREP residual quads back to back (one memory round trip per
+      // slab instead of one per quad), then combine and store.
+      f32x4 bias[4], rv[4][MREP];
+      unsigned off[4][MREP];
+      int cog[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int np = nbase + nr * 32 + 8 * g + 4 * lhi;      // GEMM row of this quad
@@ -306,17 +312,28 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
           co = np - ab * C;
           shift = (unsigned)((ab >> 1) * OWs + (ab & 1)) * (unsigned)C;
         }
-        const f32x4 bias = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
-        const f32x4 mul = mulp ? *reinterpret_cast<const f32x4*>(mulp + co) : f32x4{1.f, 1.f, 1.f, 1.f};
-        const f32x4 add = addp ? *reinterpret_cast<const f32x4*>(addp + co) : zero4;
+        cog[g] = co;
+        bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
 #pragma unroll
         for (int mr = 0; mr < MREP; ++mr) {
+          off[g][mr] = eo[mr] + shift + (unsigned)co;
+          rv[g][mr] = rimg ? *reinterpret_cast<const f32x4*>(rimg + off[g][mr]) : zero4;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
+        if (mulp) {
+          mul = *reinterpret_cast<const f32x4*>(mulp + cog[g]);
+          add = *reinterpret_cast<const f32x4*>(addp + cog[g]);
+        }
+#pragma unroll
+        for (int mr = 0; mr < MREP; ++mr) {
+          const f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} +
+                          bias[g] + rv[g][mr];
           if (ok[mr]) {
-            const unsigned o = eo[mr] + shift + (unsigned)co;
-            f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias;
-            if (rimg) v += *reinterpret_cast<const f32x4*>(rimg + o);
-            if (yraw) *reinterpret_cast<f32x4*>(yraw + o) = v;
-            if (yact) *reinterpret_cast<f32x4*>(yact + o) = lrelu4(v * mul + add, a.slope);
+            if (yraw) *reinterpret_cast<f32x4*>(yraw + off[g][mr]) = v;
+            if (yact) *reinterpret_cast<f32x4*>(yact + off[g][mr]) = lrelu4(v * mul + add, a.slope);
           }
         }
       }
@@ -388,7 +405,7 @@ int pick_mrep(const virnet_conv_desc* d) {
   if (d->stride == 2 || d->nrep >= 4) return 1;   // MREP=2 with >= 4 channel blocks would spill (256-VGPR budget)
   static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();  // tuning knob
   const int oh = d->h, ow = d->w;
-  if (forced == 1 || forced == 2 || (forced == 3 && d->ks == 3 && d->nrep == 2)) return forced;
+  if (forced == 1 || forced == 2) return forced;
   const long wg8 = (long)d->n * ((oh + 7) / 8) * ((ow + 31) / 32) * (d->n_pad / (32 * d->nrep));
   return wg8 < 2048 ? 1 : 2;
 }
@@ -467,7 +484,7 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
 #define VIRNET_CASE(KS_, S_, M_, N_) \
   if (d->ks == KS_ && d->stride == S_ && mrep == M_ && d->nrep == N_) return launch<KS_, S_, M_, N_>(k, st)
   VIRNET_CASE(3, 1, 1, 1); VIRNET_CASE(3, 1, 2, 1);
-  VIRNET_CASE(3, 1, 1, 2); VIRNET_CASE(3, 1, 2, 2); VIRNET_CASE(3, 1, 3, 2);
+  VIRNET_CASE(3, 1, 1, 2); VIRNET_CASE(3, 1, 2, 2);
   VIRNET_CASE(3, 1, 1, 3); VIRNET_CASE(3, 1, 2, 3);
   VIRNET_CASE(3, 1, 1, 4); VIRNET_CASE(3, 1, 1, 5); VIRNET_CASE(3, 1, 1, 7);
   VIRNET_CASE(3, 2, 1, 1); VIRNET_CASE(3, 2, 1, 2); VIRNET_CASE(3, 2, 1, 3); VIRNET_CASE(3, 2, 1, 4); VIRNET_CASE(3, 2, 1, 5);
