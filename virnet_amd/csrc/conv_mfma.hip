@@ -56,6 +56,7 @@ struct KArgs {
   int N, H, W, Cin;        // input
   int OH, OW;              // GEMM pixel grid (conv output; for CONVT the INPUT grid)
   int NP;                  // padded GEMM-N (output channel) extent
+  int nrep_p;              // 32-channel slabs per channel block in the PACKED weights (a multiple of the kernel's NREP)
   int cout;                // real channels of the stored tensor
   int ntx, nty, ntiles, tiles_per_xcd;
   int epi, nchw_op, crop_h, crop_w, res_sf, in_act;
@@ -114,7 +115,11 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   const int nchunks = a.Cin >> 4;
   const int nstages = nchunks * NTAPS;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
-  const float* const wcb = a.wp + (size_t)cb * nstages * (WSTAGE / 4);
+  // The packed weights hold nrep_p slabs per channel block; this instantiation owns NREP of them (NREP divides nrep_p), so a
+  // small grid can be cut into more, shorter workgroups without repacking.
+  const int slab0 = (cb * NREP) % a.nrep_p;
+  const int wstage_p = a.nrep_p * 512;             // floats of one packed stage
+  const float* const wcb = a.wp + (size_t)((cb * NREP) / a.nrep_p) * nstages * wstage_p;
 
   // Input piece k of this thread: q = k*256+tid -> (pixel p, 16-B slot s).  The global load is ALWAYS issued, from an address
   // clamped into the image; the zero fill of out-of-image halo pixels is applied when the registers are written to LDS, so
@@ -146,9 +151,13 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   };
   // weight stage `stage` -> registers (linear 16-B pieces; the packed global image IS the LDS image)
   auto load_w = [&](int stage, f32x4 (&r)[WPT]) {
-    const float* const p = wcb + (size_t)stage * (WSTAGE / 4);
+    const float* const p = wcb + (size_t)stage * wstage_p;
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + min(i * 256 + tid, WPIECE - 1) * 4);
+    for (int i = 0; i < WPT; ++i) {
+      const int qq = min(i * 256 + tid, WPIECE - 1);          // piece of THIS kernel's stage image [j][NREP][lane]
+      const int j = qq / (NREP * 64), r64 = qq - j * (NREP * 64);
+      r[i] = *reinterpret_cast<const f32x4*>(p + ((j * a.nrep_p + slab0) * 64 + r64) * 4);
+    }
   };
   auto store_w = [&](int slot, const f32x4 (&r)[WPT]) {
 #pragma unroll
@@ -400,21 +409,30 @@ int pick_nrep(int nblocks32) {
   return 1;
 }
 
-// Small grids (deep U-Net levels, single images) use 4-row tiles so the 256 CUs still see >= 2 workgroups each.
-int pick_mrep(const virnet_conv_desc* d) {
-  if (d->stride == 2 || d->nrep >= 4) return 1;   // MREP=2 with >= 4 channel blocks would spill (256-VGPR budget)
-  static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();  // tuning knob
-  const int oh = d->h, ow = d->w;
-  if (forced == 1 || forced == 2) return forced;
-  const long wg8 = (long)d->n * ((oh + 7) / 8) * ((ow + 31) / 32) * (d->n_pad / (32 * d->nrep));
-  return wg8 < 2048 ? 1 : 2;
+// Tile choice.  Large grids: 8-row tiles x all packed slabs (fewest operand fetches per MFMA).  Smaller grids trade that for
+// more, shorter workgroups: 4-row tiles, then single-slab workgroups (NREP=1 reads its slab out of the wider packing), so deep
+// U-Net levels and single images still cover the 256 CUs and no workgroup's serial K loop dominates the launch.
+struct TileSel { int mrep, nrep; };
+TileSel pick_tile(const virnet_conv_desc* d) {
+  static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();    // tuning knobs
+  static const int forced_n = [] { const char* e = getenv("VIRNET_FORCE_NREP"); return e ? atoi(e) : 0; }();
+  const long tiles8 = (long)d->n * ((d->h / d->stride + 7) / 8) * ((d->w / d->stride + 31) / 32);
+  const long tiles4 = (long)d->n * ((d->h / d->stride + 3) / 4) * ((d->w / d->stride + 31) / 32);
+  const long cbs = d->n_pad / (32 * d->nrep);
+  TileSel t{1, d->nrep};
+  if (d->stride == 1 && d->nrep <= 3 && tiles8 * cbs >= 2048) t.mrep = 2;      // MREP=2 with >= 4 slabs would spill
+  else if (tiles4 * cbs < 1024 && d->nrep > 1) t.nrep = 1;
+  if ((forced == 1 || forced == 2) && d->stride == 1 && d->nrep <= 3) t.mrep = forced;
+  if (forced_n == 1 || forced_n == d->nrep) t.nrep = forced_n;
+  return t;
 }
 
 }  // namespace
 
 extern "C" int virnet_conv_mfma_variant(const virnet_conv_desc* d, int out[4]) {
   VIRNET_REQUIRE(d && out, "virnet_conv_mfma_variant: NULL pointer");
-  out[0] = d->ks; out[1] = d->stride; out[2] = pick_mrep(d); out[3] = d->nrep;
+  const TileSel t = pick_tile(d);
+  out[0] = d->ks; out[1] = d->stride; out[2] = t.mrep; out[3] = t.nrep;
   return 0;
 }
 
@@ -480,9 +498,11 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
       return virnet::set_error("virnet_conv_mfma: unknown epilogue %d", d->epi);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int mrep = pick_mrep(d);
+  const TileSel ts = pick_tile(d);
+  const int mrep = ts.mrep;
+  k.nrep_p = d->nrep;
 #define VIRNET_CASE(KS_, S_, M_, N_) \
-  if (d->ks == KS_ && d->stride == S_ && mrep == M_ && d->nrep == N_) return launch<KS_, S_, M_, N_>(k, st)
+  if (d->ks == KS_ && d->stride == S_ && mrep == M_ && ts.nrep == N_) return launch<KS_, S_, M_, N_>(k, st)
   VIRNET_CASE(3, 1, 1, 1); VIRNET_CASE(3, 1, 2, 1);
   VIRNET_CASE(3, 1, 1, 2); VIRNET_CASE(3, 1, 2, 2);
   VIRNET_CASE(3, 1, 1, 3); VIRNET_CASE(3, 1, 2, 3);
@@ -492,5 +512,5 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   VIRNET_CASE(1, 1, 1, 1); VIRNET_CASE(1, 1, 2, 1); VIRNET_CASE(1, 1, 1, 2); VIRNET_CASE(1, 1, 2, 2); VIRNET_CASE(1, 1, 1, 3);
   VIRNET_CASE(1, 1, 2, 3); VIRNET_CASE(1, 1, 1, 4); VIRNET_CASE(1, 1, 1, 5); VIRNET_CASE(1, 1, 1, 7);
 #undef VIRNET_CASE
-  return virnet::set_error("virnet_conv_mfma: no kernel for ks=%d stride=%d mrep=%d nrep=%d", d->ks, d->stride, mrep, d->nrep);
+  return virnet::set_error("virnet_conv_mfma: no kernel for ks=%d stride=%d mrep=%d nrep=%d", d->ks, d->stride, mrep, ts.nrep);
 }
