@@ -264,3 +264,19 @@ def test_repack_follows_parameter_updates():
     r1, _ = ops.conv_mfma(nhwc(x), cp.packed())
     ref = F.conv2d(x, cp.weight.detach().cpu(), None, padding=1)
     assert maxerr(nchw(r1), ref) <= TOL and maxerr(nchw(r0), ref) > 1e-2
+
+
+def test_conv_tensor_beyond_4gib():
+    """Image bases are 64-bit, in-image offsets 32-bit: a 4.4 GB NHWC tensor (> 2**32 bytes, > 2**30 elements) must convolve
+    its LAST image exactly like that image alone (288 GB parts hold batches this large; BASELINE configs[2] is 6.4 GB/tensor)."""
+    n, h, w, c = 44, 512, 512, 96
+    assert n * h * w * c * 4 > 2 ** 32
+    cp = make_conv(c, c).cuda()
+    x = torch.empty(n, h, w, c, device="cuda")
+    x.uniform_(-1, 1)
+    raw, _ = ops.conv_mfma(x, cp.packed(), in_slope=0.2, res=x, want_raw=True)
+    for i in (0, n - 1):
+        ri, _ = ops.conv_mfma(x[i:i + 1].contiguous(), cp.packed(), in_slope=0.2, res=x[i:i + 1].contiguous(), want_raw=True)
+        assert torch.equal(ri[0], raw[i])
+    ref = F.conv2d(F.leaky_relu(x[n - 1, :40, :40].permute(2, 0, 1)[None].cpu(), 0.2), cp.weight.detach().cpu(), cp.bias.detach().cpu(), padding=1)
+    assert maxerr(raw[n - 1, :38, :38].permute(2, 0, 1).cpu(), ref[0, :, :38, :38] + x[n - 1, :38, :38].permute(2, 0, 1).cpu()) <= TOL
