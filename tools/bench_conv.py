@@ -22,9 +22,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="l0,l1,l2")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--down", action="store_true", help="time the stride-2 down convs (96->192 @256^2, 192->288 @128^2) instead")
     ap.add_argument("--mode", default="res", choices=["dual", "act", "raw", "res", "pre"])
     args = ap.parse_args()
     torch.manual_seed(0)
+    if args.down:
+        for (n, h, w, cin, cout) in [(32, 256, 256, 96, 192), (32, 128, 128, 192, 288)]:
+            cp = ConvParam(cin, cout, 3, stride=2).cuda()
+            x = torch.rand(n, h, w, cin, device="cuda") - 0.5
+            pw = cp.packed()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            times = []
+            for it in range(args.iters + 3):
+                e0.record(); ops.conv_mfma(x, pw, stride=2, want_raw=True); e1.record(); e1.synchronize()
+                if it >= 3:
+                    times.append(e0.elapsed_time(e1))
+            times.sort()
+            flops = 2.0 * n * (h // 2) * (w // 2) * cin * cout * 9
+            print(f"down {cin}->{cout} @{h}: median {times[len(times) // 2]:.3f} ms  {flops / times[len(times) // 2] / 1e9:.1f} TFLOP/s", flush=True)
+        return
     for name in args.shapes.split(","):
         n, h, w, c = SHAPES[name]
         cp = ConvParam(c, c, 3).cuda()

@@ -70,22 +70,25 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
   return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
 }
 
-template <int KS, int STRIDE, int MREP, int NREP>
-__global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1 : 2)) void conv_mfma_kernel(const KArgs a) {
-  constexpr int TH = 4 * MREP;
+// NW = waves per workgroup (4, or 8 for the stride-2 tile whose 141 KB of pixel buffers leave room for only one workgroup per CU:
+// eight waves keep two per SIMD).
+template <int KS, int STRIDE, int MREP, int NREP, int NW>
+__global__ __launch_bounds__(64 * NW, ((NW == 8) ? 2 : (NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1 : 2)) void conv_mfma_kernel(const KArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int TH = NW * MREP;
   constexpr int PAD = KS / 2;
   constexpr int IH = (TH - 1) * STRIDE + KS;
   constexpr int IW = 31 * STRIDE + KS;
   constexpr int NPIX = IH * IW;
   constexpr int NPIECE = NPIX * 4;                 // 16-B pieces of one input chunk
   constexpr int NTAPS = KS * KS;
-  constexpr int PPT = (NPIECE + 255) / 256;        // input pieces per thread per chunk
+  constexpr int PPT = (NPIECE + NT - 1) / NT;        // input pieces per thread per chunk
   constexpr int LPT = (PPT + NTAPS - 1) / NTAPS;   // ... issued per tap
   constexpr int NB = 32 * NREP;
   constexpr int IN_BYTES = NPIX * 64;
   constexpr int WSTAGE = NREP * 2048;              // bytes of one tap's weight fragments: [j][nr][lane][16 B]
   constexpr int WPIECE = NREP * 128;               // ... in 16-B pieces
-  constexpr int WPT = (WPIECE + 255) / 256;
+  constexpr int WPT = (WPIECE + NT - 1) / NT;
   constexpr int RING = 3;                          // weight ring slots (NTAPS % RING == 0 or NTAPS == 1)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   // clamped into the image; the zero fill of out-of-image halo pixels is applied when the registers are written to LDS, so
   // nothing but the load writes its destination registers and no wait is needed before the MFMAs that hide its latency.
   auto in_addr = [&](int k, int chunk, int& off, int& dst, bool& inb) {
-    const int qq = k * 256 + tid;
+    const int qq = k * NT + tid;
     const bool has = (k < PPT) && (qq < NPIECE);
     const int qc = has ? qq : 0;
     const int p = qc >> 2, s = qc & 3;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
     const float* const p = wcb + (size_t)stage * wstage_p;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
-      const int qq = min(i * 256 + tid, WPIECE - 1);          // piece of THIS kernel's stage image [j][NREP][lane]
+      const int qq = min(i * NT + tid, WPIECE - 1);          // piece of THIS kernel's stage image [j][NREP][lane]
       const int j = qq / (NREP * 64), r64 = qq - j * (NREP * 64);
       r[i] = *reinterpret_cast<const f32x4*>(p + ((j * a.nrep_p + slab0) * 64 + r64) * 4);
     }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   auto store_w = [&](int slot, const f32x4 (&r)[WPT]) {
 #pragma unroll
     for (int i = 0; i < WPT; ++i)
-      if (i * 256 + tid < WPIECE) *reinterpret_cast<f32x4*>(w_lds + slot * WSTAGE + (i * 256 + tid) * 16) = r[i];
+      if (i * NT + tid < WPIECE) *reinterpret_cast<f32x4*>(w_lds + slot * WSTAGE + (i * NT + tid) * 16) = r[i];
   };
   // fragments of half-step (tap, j): weights of ring slot `slot`, pixels of tile buffer `buf`
   auto read_w = [&](int slot, int j, f32x4 (&w)[NREP]) {
@@ -379,13 +382,13 @@ __global__ __launch_bounds__(256, ((NREP >= 7 || (NREP >= 5 && STRIDE == 2)) ? 1
   }
 }
 
-template <int KS, int STRIDE, int MREP, int NREP>
+template <int KS, int STRIDE, int MREP, int NREP, int NW = 4>
 int launch(const KArgs& ka, hipStream_t st) {
-  constexpr int TH = 4 * MREP;
+  constexpr int TH = NW * MREP;
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
   constexpr int LDS = 2 * IH * IW * 64 + 3 * NREP * 2048;
   static bool attr_done = false;
-  auto kern = conv_mfma_kernel<KS, STRIDE, MREP, NREP>;
+  auto kern = conv_mfma_kernel<KS, STRIDE, MREP, NREP, NW>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_mfma): %s", hipGetErrorString(e));
@@ -398,7 +401,7 @@ int launch(const KArgs& ka, hipStream_t st) {
   k.tiles_per_xcd = (k.ntiles + 7) / 8;
   const int ncb = k.NP / (32 * NREP);
   const unsigned grid = (unsigned)(8 * k.tiles_per_xcd * ncb);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, k);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDS, st, k);
   return virnet::check_launch("conv_mfma launch");
 }
 
@@ -412,18 +415,22 @@ int pick_nrep(int nblocks32) {
 // Tile choice.  Large grids: 8-row tiles x all packed slabs (fewest operand fetches per MFMA).  Smaller grids trade that for
 // more, shorter workgroups: 4-row tiles, then single-slab workgroups (NREP=1 reads its slab out of the wider packing), so deep
 // U-Net levels and single images still cover the 256 CUs and no workgroup's serial K loop dominates the launch.
-struct TileSel { int mrep, nrep; };
+struct TileSel { int mrep, nrep, nw; };
 TileSel pick_tile(const virnet_conv_desc* d) {
   static const int forced = [] { const char* e = getenv("VIRNET_FORCE_MREP"); return e ? atoi(e) : 0; }();    // tuning knobs
   static const int forced_n = [] { const char* e = getenv("VIRNET_FORCE_NREP"); return e ? atoi(e) : 0; }();
   const long tiles8 = (long)d->n * ((d->h / d->stride + 7) / 8) * ((d->w / d->stride + 31) / 32);
   const long tiles4 = (long)d->n * ((d->h / d->stride + 3) / 4) * ((d->w / d->stride + 31) / 32);
   const long cbs = d->n_pad / (32 * d->nrep);
-  TileSel t{1, d->nrep};
+  TileSel t{1, d->nrep, 4};
   if (d->stride == 1 && d->nrep <= 3 && tiles8 * cbs >= 2048) t.mrep = 2;      // MREP=2 with >= 4 slabs would spill
   else if (tiles4 * cbs < 1024 && d->nrep > 1) t.nrep = 1;
+  if (d->stride == 2 && d->nrep <= 4 && tiles8 * cbs >= 512) t.nw = 8;       // one workgroup per CU either way: give it 8 waves
+  static const int forced_w = [] { const char* e = getenv("VIRNET_FORCE_NW"); return e ? atoi(e) : 0; }();
+  if (forced_w == 4) t.nw = 4;
   if ((forced == 1 || forced == 2) && d->stride == 1 && d->nrep <= 3) t.mrep = forced;
   if (forced_n == 1 || forced_n == d->nrep) t.nrep = forced_n;
+  if (t.nrep != d->nrep) t.nw = 4;
   return t;
 }
 
@@ -507,6 +514,11 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   VIRNET_CASE(3, 1, 1, 2); VIRNET_CASE(3, 1, 2, 2);
   VIRNET_CASE(3, 1, 1, 3); VIRNET_CASE(3, 1, 2, 3);
   VIRNET_CASE(3, 1, 1, 4); VIRNET_CASE(3, 1, 1, 5); VIRNET_CASE(3, 1, 1, 7);
+  if (d->ks == 3 && d->stride == 2 && ts.nw == 8) {
+    if (ts.nrep == 2) return launch<3, 2, 1, 2, 8>(k, st);
+    if (ts.nrep == 3) return launch<3, 2, 1, 3, 8>(k, st);
+    if (ts.nrep == 4) return launch<3, 2, 1, 4, 8>(k, st);
+  }
   VIRNET_CASE(3, 2, 1, 1); VIRNET_CASE(3, 2, 1, 2); VIRNET_CASE(3, 2, 1, 3); VIRNET_CASE(3, 2, 1, 4); VIRNET_CASE(3, 2, 1, 5);
   VIRNET_CASE(3, 2, 1, 7);
   VIRNET_CASE(1, 1, 1, 1); VIRNET_CASE(1, 1, 2, 1); VIRNET_CASE(1, 1, 1, 2); VIRNET_CASE(1, 1, 2, 2); VIRNET_CASE(1, 1, 1, 3);
