@@ -42,6 +42,12 @@ int virnet_device_count(void);
  * `cin_pad` (multiple of 16) and `n_pad` (multiple of 32*nrep) give the zero-padded GEMM extents; `nrep` is the
  * number of 32-column blocks one workgroup owns (see virnet_conv_plan).
  * ---------------------------------------------------------------------------------------------- */
+/*   kind 2: the input-gradient ("dgrad") weights of a 3x3 conv, W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]: pass the forward
+ *           OIHW tensor, cout/cin are the FORWARD counts; the packed GEMM has cin rows (n_pad covers cin) and cout_fwd
+ *           contraction channels (cin_pad covers cout).  Used with stride 1 (a stride-2 conv's dgrad runs on the zero-stuffed
+ *           gradient, virnet_zero_stuff2).
+ *   kind 3: dgrad weights of the 2x2/s2 transposed conv: a 1x1 GEMM over the space-to-depth gradient
+ *           (virnet_space_to_depth2): W'[ci][ab*cout+co] = Wt[ci][co][a][b]; n_pad covers cin, cin_pad covers 4*cout. */
 size_t virnet_packed_weight_floats(int ks, int cin_pad, int n_pad);
 int virnet_pack_weight(const float* w, int kind, int cout, int cin, int ks, int cin_pad, int n_pad, int nrep,
                        float* packed, void* stream);
@@ -73,6 +79,8 @@ typedef struct virnet_conv_desc {
                           EPI_NCHW : NCHW [n][cout][crop_h][crop_w] (the `+ x_in` of AttResUNet.py:173) or NULL */
   const float* mul;    /* [n][cout] SFT scale applied to y_act (AttResUNet.py:57-58) or NULL (=1) */
   const float* add;    /* [n][cout] SFT shift applied to y_act or NULL (=0) */
+  const float* mask;   /* EPI_NHWC only, backward passes: tensor of the output's shape; acc is multiplied by lrelu'(mask) =
+                          (mask > 0 ? 1 : mask_slope) BEFORE res is added (d_pre = d_act * lrelu'(saved), AttResUNet.py:55,58) */
   const float* in_mul; /* [n][cin_pad] SFT scale applied to x while it is staged (AttResUNet.py:54-55) or NULL (=1) */
   const float* in_add; /* [n][cin_pad] SFT shift applied to x while it is staged or NULL (=0) */
   float* y_raw;        /* conv + bias (+res); NULL = not stored */
@@ -92,6 +100,7 @@ typedef struct virnet_conv_desc {
                           applied to the pixels on their way into LDS; padding stays zero AFTER the activation. 0: plain x */
   float in_slope;      /* LeakyReLU slope of the input activation */
   float slope;         /* LeakyReLU slope of y_act */
+  float mask_slope;    /* slope of the LeakyReLU whose derivative `mask` selects */
   float clamp_lo, clamp_hi; /* VIRNET_NCHW_EXPCLAMP: y = exp(clamp(v, lo, hi))  (VIRNet.py:43) */
 } virnet_conv_desc;
 
@@ -140,6 +149,35 @@ typedef struct virnet_pack_desc {
   int hp, wp;
 } virnet_pack_desc;
 int virnet_pack_input(const virnet_pack_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training step: weight / bias gradients and the layout helpers of the input-gradient convs.
+ * Input gradients themselves are virnet_conv_mfma launches with kind-2 / kind-3 packed weights and the `mask` epilogue.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct virnet_wgrad_desc {
+  const float* x;       /* NHWC [n][h][w][cx]: the conv's forward input */
+  const float* dy;      /* NHWC [n][oh][ow][cy]: gradient of the conv's output (transposed: space-to-depth gradient, cy = 4*cout) */
+  const float* in_mul;  /* the forward conv's staging transform (lrelu(x*in_mul+in_add)), or NULL */
+  const float* in_add;
+  float* dw;            /* += : [cout][cin][ks][ks] (OIHW) or, transposed, [cin][cout][2][2]; zero it first (fp32 atomics) */
+  int n, h, w, cx, cy;
+  int cin, cout;        /* real channel counts (<= cx, cy) */
+  int ks, stride;       /* {3,1} {3,2} {1,1} */
+  int transposed;       /* 1: weight of ConvTranspose2d(k2,s2) */
+  int in_act;
+  float in_slope;
+} virnet_wgrad_desc;
+int virnet_conv_wgrad(const virnet_wgrad_desc* d, void* stream);
+/* db[c] += sum over pixels of dy[p][c], c < cvalid (NHWC rows of `c` stored channels, c % 4 == 0); zero db first */
+int virnet_colsum(const float* dy, float* db, long npix, int c, int cvalid, void* stream);
+/* z[n][2h][2w][c] = dy at even positions, 0 elsewhere: the stride-2 conv's dgrad is a stride-1 conv of z (AttResUNet.py:67) */
+int virnet_zero_stuff2(const float* dy, float* z, int n, int h, int w, int c, void* stream);
+/* out[n][h][w][(a*2+b)*c + k] = dy[n][2h+a][2w+b][k]: the transposed conv's dgrad / wgrad operand (AttResUNet.py:80) */
+int virnet_space_to_depth2(const float* dy, float* out, int n, int h, int w, int c, void* stream);
+/* Adjoint of virnet_pack_input for ONE map channel: dmap[n][h][w] (+)= sum over padded positions that read (y,x) of
+ * drec[n][hp][wp][crec][chan] * (map_sqrt ? 0.5/sqrt(map[y][x]) : 1)   (reflect pad of util_net.py:20-25, sqrt of VIRNet.py:44) */
+int virnet_pack_input_backward(const float* drec, int crec, int chan, const float* map, float* dmap, int n, int h, int w, int hp,
+                               int wp, int map_sqrt, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KNet pieces (networks/KNet.py) and the SFT generator (networks/AttResUNet.py:11-32).  Small, latency-bound kernels.

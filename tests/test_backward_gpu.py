@@ -1,0 +1,122 @@
+"""GPU parity of the training-step kernels against torch autograd on the CPU oracle's ops.
+
+Weight/bias gradients contract over every pixel of the batch (fp32 atomics, arbitrary order): they are held to 2e-5 of the
+gradient's own scale; input gradients are ordinary convs (<= 2e-5 on O(1) data)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+from virnet_amd import ops
+from virnet_amd.networks.params import ConvParam
+from test_ops_gpu import make_conv, maxerr, nchw, nhwc, rnd
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def autograd_conv(x, w, b, dy, *, stride=1, in_slope=None, mul=None, add=None):
+    x = x.clone().requires_grad_(True); w = w.clone().requires_grad_(True); b = b.clone().requires_grad_(True)
+    a = x
+    if mul is not None:
+        a = a * mul.view(*mul.shape, 1, 1) + add.view(*add.shape, 1, 1)
+    if in_slope is not None:
+        a = F.leaky_relu(a, in_slope)
+    y = F.conv2d(a, w, b, stride=stride, padding=w.shape[-1] // 2)
+    y.backward(dy)
+    return x.grad, w.grad, b.grad
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n,act,sft", [(96, 96, 17, 33, 2, True, False), (64, 64, 12, 40, 2, False, False),
+                                                    (32, 96, 9, 20, 3, True, True), (192, 192, 8, 32, 1, True, False),
+                                                    (96, 160, 10, 35, 1, False, False)])
+def test_wgrad_bias_3x3(cin, cout, h, w, n, act, sft):
+    cp = make_conv(cin, cout)
+    x, dy = rnd(n, cin, h, w, seed=60), rnd(n, cout, h, w, seed=61)
+    mul, add = (rnd(n, cin, seed=62, lo=0.2, hi=1.0), rnd(n, cin, seed=63)) if sft else (None, None)
+    _, dw_ref, db_ref = autograd_conv(x, cp.weight.detach(), cp.bias.detach(), dy, in_slope=0.2 if act else None, mul=mul, add=add)
+    dw = ops.conv_wgrad(nhwc(x), nhwc(dy), tuple(cp.weight.shape), in_slope=0.2 if act else None,
+                        in_mul=None if mul is None else mul.cuda(), in_add=None if add is None else add.cuda())
+    db = ops.colsum(nhwc(dy))
+    assert relerr(dw.cpu(), dw_ref) <= TOL and relerr(db.cpu(), db_ref) <= TOL
+
+
+def test_wgrad_thin_layers():
+    """tail 96->3 (gradient stored as a 16-channel record) and head 4->96 (input stored as a 16-channel record)."""
+    x, dy3 = rnd(2, 96, 13, 37, seed=64), rnd(2, 3, 13, 37, seed=65)
+    w = rnd(3, 96, 3, 3, seed=66) * 0.1
+    _, dw_ref, db_ref = autograd_conv(x, w, torch.zeros(3), dy3)
+    dy16 = torch.zeros(2, 16, 13, 37); dy16[:, :3] = dy3
+    dw = ops.conv_wgrad(nhwc(x), nhwc(dy16), (3, 96, 3, 3))
+    assert relerr(dw.cpu(), dw_ref) <= TOL and relerr(ops.colsum(nhwc(dy16), 3).cpu(), db_ref) <= TOL
+    x4, dy = rnd(2, 4, 13, 37, seed=67), rnd(2, 96, 13, 37, seed=68)
+    w2 = rnd(96, 4, 3, 3, seed=69) * 0.2
+    _, dw2_ref, _ = autograd_conv(x4, w2, torch.zeros(96), dy)
+    x16 = torch.zeros(2, 16, 13, 37); x16[:, :4] = x4
+    dw2 = ops.conv_wgrad(nhwc(x16), nhwc(dy), (96, 4, 3, 3))
+    assert relerr(dw2.cpu(), dw2_ref) <= TOL
+
+
+def test_dgrad_3x3_with_mask_and_residual():
+    """dx = dout + dgrad(d_f1) * lrelu'(x): the backward of conv(lrelu(x)) inside a residual block (AttResUNet.py:55,59)."""
+    cp = make_conv(96, 96)
+    x, dy, dout = rnd(2, 96, 11, 34, seed=70), rnd(2, 96, 11, 34, seed=71), rnd(2, 96, 11, 34, seed=72)
+    dx_ref, _, _ = autograd_conv(x, cp.weight.detach(), cp.bias.detach(), dy, in_slope=0.2)
+    cp.cuda()
+    pw = ops.pack_weight(cp.weight, None, dgrad=True)
+    dx, _ = ops.conv_mfma(nhwc(dy), pw, mask=nhwc(x), mask_slope=0.2, res=nhwc(dout), want_raw=True)
+    assert maxerr(nchw(dx), dx_ref + dout) <= TOL
+    # Cin != Cout and no mask
+    cp2 = make_conv(64, 160)
+    x2, dy2 = rnd(1, 64, 9, 33, seed=73), rnd(1, 160, 9, 33, seed=74)
+    dx2_ref, _, _ = autograd_conv(x2, cp2.weight.detach(), cp2.bias.detach(), dy2)
+    cp2.cuda()
+    dx2, _ = ops.conv_mfma(nhwc(dy2), ops.pack_weight(cp2.weight, None, dgrad=True), want_raw=True)
+    assert tuple(dx2.shape) == (1, 9, 33, 64) and maxerr(nchw(dx2), dx2_ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(96, 192, 16, 40, 2), (192, 288, 8, 64, 1), (96, 160, 10, 6, 1)])
+def test_stride2_conv_backward(cin, cout, h, w, n):
+    """DownBlock.downsampler (AttResUNet.py:67): dgrad = 3x3 conv of the zero-stuffed gradient, wgrad with stride 2."""
+    cp = make_conv(cin, cout, stride=2)
+    x, dy = rnd(n, cin, h, w, seed=75), rnd(n, cout, h // 2, w // 2, seed=76)
+    dx_ref, dw_ref, db_ref = autograd_conv(x, cp.weight.detach(), cp.bias.detach(), dy, stride=2)
+    cp.cuda()
+    z = ops.zero_stuff2(nhwc(dy))
+    dx, _ = ops.conv_mfma(z, ops.pack_weight(cp.weight, None, dgrad=True), want_raw=True)
+    dw = ops.conv_wgrad(nhwc(x), nhwc(dy), tuple(cp.weight.shape), stride=2)
+    assert maxerr(nchw(dx), dx_ref) <= TOL and relerr(dw.cpu(), dw_ref) <= TOL
+    assert relerr(ops.colsum(nhwc(dy)).cpu(), db_ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(192, 96, 9, 20, 2), (288, 192, 8, 8, 1), (160, 96, 6, 7, 2)])
+def test_transposed_conv_backward(cin, cout, h, w, n):
+    """UpBlock.upsampler (AttResUNet.py:80): dgrad / wgrad as pointwise GEMMs over the space-to-depth gradient."""
+    cp = make_conv(cin, cout, ks=2, stride=2, transposed=True)
+    x = rnd(n, cin, h, w, seed=77).requires_grad_(True)
+    wt = cp.weight.detach().clone().requires_grad_(True)
+    dy = rnd(n, cout, 2 * h, 2 * w, seed=78)
+    F.conv_transpose2d(x, wt, None, stride=2).backward(dy)
+    cp.cuda()
+    s2d = ops.space_to_depth2(nhwc(dy))
+    assert tuple(s2d.shape) == (n, h, w, 4 * cout)
+    dx, _ = ops.conv_mfma(s2d, ops.pack_weight(cp.weight, None, transposed=True, dgrad=True), want_raw=True)
+    dw = ops.conv_wgrad(nhwc(x.detach()), s2d, tuple(cp.weight.shape), transposed=True)
+    assert maxerr(nchw(dx), x.grad) <= TOL and relerr(dw.cpu(), wt.grad) <= TOL
+
+
+def test_pack_input_backward_is_the_adjoint():
+    """d sigma from the gradient of the padded 16-channel records: reflect-pad adjoint + d sqrt (util_net.py:20-25, VIRNet.py:44)."""
+    sig = rnd(2, 1, 37, 45, seed=79, lo=0.1, hi=2.0).requires_grad_(True)
+    g = rnd(2, 40, 48, 16, seed=80)
+    cpu_ref.pad_to_multiple(sig.sqrt(), 4).backward(g[..., 3].unsqueeze(1))
+    got = ops.pack_input_backward(g.cuda(), 3, (37, 45), map_=sig.detach().cuda(), map_sqrt=True)
+    assert maxerr(got.cpu(), sig.grad) <= 1e-5
+    acc = torch.ones(2, 1, 37, 45, device="cuda")
+    ops.pack_input_backward(g.cuda(), 3, (37, 45), map_=sig.detach().cuda(), map_sqrt=True, into=acc)
+    assert maxerr(acc.cpu(), sig.grad + 1) <= 1e-5

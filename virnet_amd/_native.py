@@ -27,12 +27,12 @@ class ConvPlan(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("wpack", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
-        ("mul", C.c_void_p), ("add", C.c_void_p), ("in_mul", C.c_void_p), ("in_add", C.c_void_p),
+        ("mul", C.c_void_p), ("add", C.c_void_p), ("mask", C.c_void_p), ("in_mul", C.c_void_p), ("in_add", C.c_void_p),
         ("y_raw", C.c_void_p), ("y_act", C.c_void_p),
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cin_pad", C.c_int), ("cout", C.c_int),
         ("n_pad", C.c_int), ("nrep", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("epi", C.c_int),
         ("nchw_op", C.c_int), ("crop_h", C.c_int), ("crop_w", C.c_int), ("res_sf", C.c_int),
-        ("in_act", C.c_int), ("in_slope", C.c_float), ("slope", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+        ("in_act", C.c_int), ("in_slope", C.c_float), ("slope", C.c_float), ("mask_slope", C.c_float), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
     ]
 
 
@@ -52,6 +52,15 @@ class ThinDesc(C.Structure):
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int), ("cout", C.c_int),
         ("crop_h", C.c_int), ("crop_w", C.c_int), ("op", C.c_int), ("res_sf", C.c_int),
         ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("in_mul", C.c_void_p), ("in_add", C.c_void_p), ("dw", C.c_void_p),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cx", C.c_int), ("cy", C.c_int),
+        ("cin", C.c_int), ("cout", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("transposed", C.c_int),
+        ("in_act", C.c_int), ("in_slope", C.c_float),
     ]
 
 
@@ -82,6 +91,12 @@ SYMBOLS = [
     ("virnet_thin_weight_floats", C.c_size_t, [C.c_int]),
     ("virnet_pack_thin_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv3x3_thin", C.c_int, [C.POINTER(ThinDesc), C.c_void_p]),
+    ("virnet_conv_wgrad", C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    ("virnet_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_zero_stuff2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_space_to_depth2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_pack_input_backward", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_conv_head_s4", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
     ("virnet_gap_nchw", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -51,6 +51,7 @@ struct KArgs {
   const float* add;
   const float* in_mul;
   const float* in_add;
+  const float* mask;
   float* y_raw;
   float* y_act;
   int N, H, W, Cin;        // input
@@ -60,7 +61,7 @@ struct KArgs {
   int cout;                // real channels of the stored tensor
   int ntx, nty, ntiles, tiles_per_xcd;
   int epi, nchw_op, crop_h, crop_w, res_sf, in_act;
-  float in_slope, slope, clamp_lo, clamp_hi;
+  float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
 };
 
 __device__ __forceinline__ int swz(int p) { return (p >> 2) & 3; }
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8) ? 2 : (NREP >= 7 || (NREP >= 5 
     const int OWs = convt ? 2 * a.OW : a.OW;
     const size_t img_off = (size_t)img * (convt ? 4 : 1) * a.OH * a.OW * C;
     const float* const rimg = a.res ? a.res + img_off : nullptr;
+    const float* const mimg = a.mask ? a.mask + img_off : nullptr;
     float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
     float* const yact = a.y_act ? a.y_act + img_off : nullptr;
     const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8) ? 2 : (NREP >= 7 || (NREP >= 5 
     for (int nr = 0; nr < NREP; ++nr) {
       // per 32-channel slab: issue the 4 bias quads and all 4*MREP residual quads back to back (one memory round trip per
       // slab instead of one per quad), then combine and store.
-      f32x4 bias[4], rv[4][MREP];
+      f32x4 bias[4], rv[4][MREP], mv[4][MREP];
       unsigned off[4][MREP];
       int cog[4];
 #pragma unroll
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8) ? 2 : (NREP >= 7 || (NREP >= 5 
         for (int mr = 0; mr < MREP; ++mr) {
           off[g][mr] = eo[mr] + shift + (unsigned)co;
           rv[g][mr] = rimg ? *reinterpret_cast<const f32x4*>(rimg + off[g][mr]) : zero4;
+          if (mimg) mv[g][mr] = *reinterpret_cast<const f32x4*>(mimg + off[g][mr]);
         }
       }
 #pragma unroll
@@ -341,8 +344,13 @@ __global__ __launch_bounds__(64 * NW, ((NW == 8) ? 2 : (NREP >= 7 || (NREP >= 5 
         }
 #pragma unroll
         for (int mr = 0; mr < MREP; ++mr) {
-          const f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} +
-                          bias[g] + rv[g][mr];
+          f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} + bias[g];
+          if (mimg) {                                   // backward of a LeakyReLU: multiply by its derivative at the saved tensor
+            const f32x4 m = mv[g][mr];
+            v = f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
+                      m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+          }
+          v += rv[g][mr];
           if (ok[mr]) {
             if (yraw) *reinterpret_cast<f32x4*>(yraw + off[g][mr]) = v;
             if (yact) *reinterpret_cast<f32x4*>(yact + off[g][mr]) = lrelu4(v * mul + add, a.slope);
@@ -469,6 +477,7 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   KArgs k{};
   k.x = d->x; k.wp = d->wpack; k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
   k.in_mul = d->in_mul; k.in_add = d->in_add; k.in_act = d->in_act; k.in_slope = d->in_slope;
+  k.mask = d->mask; k.mask_slope = d->mask_slope;
   k.y_raw = d->y_raw; k.y_act = d->y_act;
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad;
   k.NP = d->n_pad; k.cout = d->cout;
@@ -482,7 +491,7 @@ extern "C" int virnet_conv_mfma(const virnet_conv_desc* d, void* stream) {
   }
   switch (d->epi) {
     case VIRNET_EPI_NHWC:
-      VIRNET_REQUIRE(d->ks == 3, "virnet_conv_mfma: NHWC store is built for the 3x3 kernels (ks=%d)", d->ks);
+      VIRNET_REQUIRE(d->ks == 3 || d->ks == 1, "virnet_conv_mfma: NHWC store needs ks 1 or 3 (ks=%d)", d->ks);
       VIRNET_REQUIRE(d->n_pad == d->cout, "virnet_conv_mfma: NHWC store needs cout (%d) to be a multiple of 32", d->cout);
       VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_mfma: no output pointer");
       break;

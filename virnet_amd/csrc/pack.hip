@@ -30,13 +30,16 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
     const int ci = c * 16 + 8 * j + 4 * (lane >> 5) + rr;
     const int n = (cb * nrep + nr) * 32 + (lane & 31);
     float v = 0.f;
-    if (ci < cin) {
-      if (kind == 0) {
-        if (n < cout) v = w[((size_t)n * cin + ci) * ntaps + t];
-      } else {
-        const int ab = n / cout, co = n - ab * cout;
-        if (ab < 4) v = w[((size_t)ci * cout + co) * 4 + ab];  // [Cin][Cout][a][b], ab = a*2+b
-      }
+    if (kind == 0) {                                   // conv: rows = cout, contraction = cin
+      if (ci < cin && n < cout) v = w[((size_t)n * cin + ci) * ntaps + t];
+    } else if (kind == 1) {                            // transposed conv as 1x1 GEMM: rows = ab*cout + co
+      const int ab = n / cout, co = n - ab * cout;
+      if (ci < cin && ab < 4) v = w[((size_t)ci * cout + co) * 4 + ab];  // [Cin][Cout][a][b], ab = a*2+b
+    } else if (kind == 2) {                            // dgrad of a 3x3 conv: rows = forward cin, contraction = forward cout, taps flipped
+      if (ci < cout && n < cin) v = w[((size_t)ci * cin + n) * ntaps + (ntaps - 1 - t)];
+    } else {                                           // dgrad of the transposed conv: rows = forward cin, contraction = ab*cout + co
+      const int ab = ci / cout, co = ci - ab * cout;
+      if (n < cin && ab < 4) v = w[((size_t)n * cout + co) * 4 + ab];
     }
     out[i] = v;
   }
@@ -73,7 +76,81 @@ __global__ void pack_input_kernel(const virnet_pack_desc d) {
   }
 }
 
+__global__ void zero_stuff2_kernel(const float4* __restrict__ dy, float4* __restrict__ z, int h, int w, int c4, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % c4);
+    size_t p = i / c4;
+    const int x = (int)(p % (2 * w)); p /= 2 * w;
+    const int y = (int)(p % (2 * h));
+    const size_t n = p / (2 * h);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!((x | y) & 1)) v = dy[((n * h + (y >> 1)) * w + (x >> 1)) * c4 + q];
+    z[i] = v;
+  }
+}
+
+__global__ void space_to_depth2_kernel(const float4* __restrict__ dy, float4* __restrict__ out, int h, int w, int c4, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i % c4);
+    size_t p = i / c4;
+    const int ab = (int)(p & 3); p >>= 2;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const size_t n = p / h;
+    out[i] = dy[((n * 2 * h + 2 * y + (ab >> 1)) * 2 * w + 2 * x + (ab & 1)) * c4 + q];
+  }
+}
+
+__global__ void pack_input_backward_kernel(const float* __restrict__ drec, int crec, int chan, const float* __restrict__ map,
+                                           float* __restrict__ dmap, int h, int w, int hp, int wp, int map_sqrt, int accumulate,
+                                           size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)((i / w) % h);
+    const size_t n = i / ((size_t)w * h);
+    // padded rows that read source row y: y itself and its mirror 2h-2-y when that lands inside [h, hp)
+    const int ym = 2 * h - 2 - y, xm = 2 * w - 2 - x;
+    const bool my = ym >= h && ym < hp, mx = xm >= w && xm < wp;
+    const float* base = drec + (n * hp * (size_t)wp) * crec + chan;
+    float g = base[((size_t)y * wp + x) * crec];
+    if (my) g += base[((size_t)ym * wp + x) * crec];
+    if (mx) g += base[((size_t)y * wp + xm) * crec];
+    if (my && mx) g += base[((size_t)ym * wp + xm) * crec];
+    if (map_sqrt) g *= 0.5f / sqrtf(map[i]);
+    dmap[i] = accumulate ? dmap[i] + g : g;
+  }
+}
+
 }  // namespace
+
+static int grid_for(size_t total) { return (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256); }
+
+extern "C" int virnet_zero_stuff2(const float* dy, float* z, int n, int h, int w, int c, void* stream) {
+  VIRNET_REQUIRE(dy && z && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "virnet_zero_stuff2: bad arguments");
+  const size_t total = (size_t)n * 2 * h * 2 * w * (c / 4);
+  hipLaunchKernelGGL(zero_stuff2_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(z), h, w, c / 4, total);
+  return virnet::check_launch("zero_stuff2 launch");
+}
+
+extern "C" int virnet_space_to_depth2(const float* dy, float* out, int n, int h, int w, int c, void* stream) {
+  VIRNET_REQUIRE(dy && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "virnet_space_to_depth2: bad arguments");
+  const size_t total = (size_t)n * h * w * 4 * (c / 4);
+  hipLaunchKernelGGL(space_to_depth2_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(out), h, w, c / 4, total);
+  return virnet::check_launch("space_to_depth2 launch");
+}
+
+extern "C" int virnet_pack_input_backward(const float* drec, int crec, int chan, const float* map, float* dmap, int n, int h, int w,
+                                          int hp, int wp, int map_sqrt, int accumulate, void* stream) {
+  VIRNET_REQUIRE(drec && dmap && n > 0 && h > 0 && w > 0 && hp >= h && wp >= w && hp - h < h && wp - w < w,
+                 "virnet_pack_input_backward: bad shape %dx%d -> %dx%d", h, w, hp, wp);
+  VIRNET_REQUIRE(chan >= 0 && chan < crec, "virnet_pack_input_backward: channel %d of %d", chan, crec);
+  VIRNET_REQUIRE(!map_sqrt || map, "virnet_pack_input_backward: map_sqrt without map");
+  const size_t total = (size_t)n * h * w;
+  hipLaunchKernelGGL(pack_input_backward_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), drec, crec,
+                     chan, map, dmap, h, w, hp, wp, map_sqrt, accumulate, total);
+  return virnet::check_launch("pack_input_backward launch");
+}
 
 extern "C" size_t virnet_packed_weight_floats(int ks, int cin_pad, int n_pad) {
   return (size_t)ks * ks * cin_pad * n_pad;
@@ -82,12 +159,14 @@ extern "C" size_t virnet_packed_weight_floats(int ks, int cin_pad, int n_pad) {
 extern "C" int virnet_pack_weight(const float* w, int kind, int cout, int cin, int ks, int cin_pad, int n_pad, int nrep,
                                   float* packed, void* stream) {
   VIRNET_REQUIRE(w && packed, "virnet_pack_weight: NULL pointer");
-  VIRNET_REQUIRE(kind == 0 || kind == 1, "virnet_pack_weight: kind=%d", kind);
-  VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= cin, "virnet_pack_weight: cin_pad=%d for cin=%d", cin_pad, cin);
-  VIRNET_REQUIRE(nrep >= 1 && n_pad % (32 * nrep) == 0, "virnet_pack_weight: n_pad=%d nrep=%d", n_pad, nrep);
-  VIRNET_REQUIRE(kind == 0 ? n_pad >= cout : (ks == 2 && n_pad == 4 * cout),
-                 "virnet_pack_weight: n_pad=%d does not cover cout=%d (kind %d, ks %d)", n_pad, cout, kind, ks);
-  const int gemm_ks = (kind == 1) ? 1 : ks;  // the transposed conv runs as a pointwise GEMM
+  VIRNET_REQUIRE(kind >= 0 && kind <= 3, "virnet_pack_weight: kind=%d", kind);
+  VIRNET_REQUIRE(nrep >= 1 && n_pad % (32 * nrep) == 0 && cin_pad % 16 == 0, "virnet_pack_weight: n_pad=%d nrep=%d cin_pad=%d", n_pad, nrep, cin_pad);
+  const int rows = kind == 0 ? cout : kind == 1 ? 4 * cout : cin;          // GEMM rows the packing must cover
+  const int contr = kind <= 1 ? cin : kind == 2 ? cout : 4 * cout;         // contraction channels
+  VIRNET_REQUIRE(n_pad >= rows && cin_pad >= contr, "virnet_pack_weight: n_pad=%d / cin_pad=%d do not cover %d rows x %d channels (kind %d)",
+                 n_pad, cin_pad, rows, contr, kind);
+  VIRNET_REQUIRE((kind == 1 || kind == 3) ? ks == 2 : (ks == 3 || ks == 1), "virnet_pack_weight: ks=%d for kind %d", ks, kind);
+  const int gemm_ks = (kind == 1 || kind == 3) ? 1 : ks;  // the transposed conv (and its dgrad) run as pointwise GEMMs
   const size_t total = virnet_packed_weight_floats(gemm_ks, cin_pad, n_pad);
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed, kind, cout, cin,

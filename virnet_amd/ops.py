@@ -87,11 +87,31 @@ def get_plan(ks: int, stride: int, cin: int, gemm_n: int) -> nat.ConvPlan:
     return plan
 
 
-def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = False, stride: int = 1) -> PackedWeight:
-    """Pack an OIHW conv weight or an IOHW (k=2,s=2) transposed-conv weight for virnet_conv_mfma."""
+def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = False, stride: int = 1,
+                dgrad: bool = False) -> PackedWeight:
+    """Pack an OIHW conv weight or an IOHW (k=2,s=2) transposed-conv weight for virnet_conv_mfma.
+
+    ``dgrad=True`` packs the INPUT-GRADIENT GEMM of the same layer instead (flipped/transposed 3x3 taps, or the pointwise GEMM
+    over the space-to-depth gradient for the transposed conv); the result is used like a forward weight with cout = forward cin."""
     lib = nat.load()
     weight = weight.detach()
     _dev_check(weight, "weight")
+    if dgrad:
+        if transposed:
+            cin, cout, kh, kw = weight.shape
+            plan = get_plan(1, 1, 4 * cout, cin)
+            kind, ks, gemm_ks = 3, 2, 1
+        else:
+            cout, cin, kh, kw = weight.shape
+            if (kh, kw) != (3, 3):
+                raise ValueError("dgrad packing handles 3x3 convs and the 2x2 transposed conv")
+            plan = get_plan(3, 1, cout, cin)
+            kind, ks, gemm_ks = 2, 3, 3
+        n = lib.virnet_packed_weight_floats(gemm_ks, plan.cin_pad, plan.n_pad)
+        out = torch.empty(n, dtype=torch.float32, device=weight.device)
+        nat.check(lib.virnet_pack_weight(nat.ptr(weight), kind, cout, cin, ks, plan.cin_pad, plan.n_pad, plan.nrep, nat.ptr(out),
+                                         nat.stream_handle()), "pack_weight(dgrad)")
+        return PackedWeight(out, None, gemm_ks, cin, (4 * cout if transposed else cout), plan.cin_pad, plan.n_pad, plan.nrep, False)
     if transposed:
         cin, cout, kh, kw = weight.shape
         if (kh, kw) != (2, 2):
@@ -118,7 +138,8 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
 def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
               mul: Optional[Tensor] = None, add: Optional[Tensor] = None, want_raw: bool = True,
               want_act: bool = False, slope: float = 0.2, in_slope: Optional[float] = None,
-              in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+              in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+              mask_slope: float = 0.2, out_channels: Optional[int] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
     """NHWC conv (or transposed conv when ``pw.transposed``) -> (raw, act), each NHWC or None.
 
     ``in_slope`` (with optional per-(image, channel) ``in_mul``/``in_add``): the conv consumes
@@ -131,18 +152,23 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         oh, ow, epi = 2 * h, 2 * w, nat.EPI_CONVT
     else:
         oh, ow, epi = h // stride, w // stride, nat.EPI_NHWC
-    raw = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_raw else None
-    act = torch.empty((n, oh, ow, pw.cout), dtype=torch.float32, device=x.device) if want_act else None
+    cstore = pw.cout if out_channels is None else out_channels      # backward of thin layers: store the 32-padded rows
+    raw = torch.empty((n, oh, ow, cstore), dtype=torch.float32, device=x.device) if want_raw else None
+    act = torch.empty((n, oh, ow, cstore), dtype=torch.float32, device=x.device) if want_act else None
+    if mask is not None:
+        _dev_check(mask, "mask")
+        if tuple(mask.shape) != (n, oh, ow, cstore):
+            raise ValueError(f"mask shape {tuple(mask.shape)} != {(n, oh, ow, cstore)}")
     for t, nm in ((res, "res"), (mul, "mul"), (add, "add"), (in_mul, "in_mul"), (in_add, "in_add")):
         if t is not None:
             _dev_check(t, nm)
     if in_mul is not None and (tuple(in_mul.shape) != (n, c) or tuple(in_add.shape) != (n, c)):
         raise ValueError(f"in_mul/in_add must be [{n}, {c}]")
-    if res is not None and tuple(res.shape) != (n, oh, ow, pw.cout):
-        raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, pw.cout)}")
+    if res is not None and tuple(res.shape) != (n, oh, ow, cstore):
+        raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, cstore)}")
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
-                     add=nat.ptr(add), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), y_raw=nat.ptr(raw),
-                     y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
+                     add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
+                     y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
                      stride=stride, epi=epi, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=int(in_slope is not None),
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
@@ -166,8 +192,8 @@ def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op:
         _dev_check(res, "res")
         if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
             raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
-    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0,
-                     in_mul=0, in_add=0, in_act=0, in_slope=0.0, y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0, mask=0,
+                     mask_slope=0.0, in_mul=0, in_add=0, in_act=0, in_slope=0.0, y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout, n_pad=pw.n_pad,
                      nrep=pw.nrep, ks=pw.ks, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
                      res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
     _launch_conv(d, 2.0 * n * h * w * pw.cin_real * pw.cout * pw.ks ** 2, "conv_mfma(nchw)")
@@ -328,3 +354,63 @@ def sft_apply(raw: Tensor, rec: Tensor, chan0: int, nchan: int, step: int, att) 
     nat.check(nat.load().virnet_sft_apply(nat.ptr(raw), nat.ptr(rec), C.byref(wt), nat.ptr(act), n, h, w, step, chan0,
                                           nat.stream_handle()), "sft_apply")
     return act
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# training step: weight / bias gradients and the layout helpers of the input-gradient convs
+# ----------------------------------------------------------------------------------------------------------------------
+def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: int = 1, transposed: bool = False,
+               in_slope: Optional[float] = None, in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None) -> Tensor:
+    """Weight gradient in the reference layout (OIHW, or IOHW 2x2 for the transposed conv) from NHWC forward input ``x`` and
+    NHWC output gradient ``dy`` (for the transposed conv: the space-to-depth gradient)."""
+    _dev_check(x, "x"); _dev_check(dy, "dy")
+    n, h, w, cx = x.shape
+    cy = dy.shape[3]
+    if transposed:
+        cin, cout, ks = weight_shape[0], weight_shape[1], 1
+    else:
+        cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
+    dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
+    d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw), n=n, h=h, w=w,
+                      cx=cx, cy=cy, cin=cin, cout=cout, ks=ks, stride=stride, transposed=int(transposed),
+                      in_act=int(in_slope is not None), in_slope=0.0 if in_slope is None else in_slope)
+    nat.check(nat.load().virnet_conv_wgrad(C.byref(d), nat.stream_handle()), "conv_wgrad")
+    return dw
+
+
+def colsum(dy: Tensor, cvalid: Optional[int] = None) -> Tensor:
+    """Bias gradient: sum of an NHWC tensor over pixels -> [cvalid]."""
+    _dev_check(dy, "dy")
+    c = dy.shape[-1]
+    cvalid = c if cvalid is None else cvalid
+    db = torch.zeros(cvalid, dtype=torch.float32, device=dy.device)
+    nat.check(nat.load().virnet_colsum(nat.ptr(dy), nat.ptr(db), dy.numel() // c, c, cvalid, nat.stream_handle()), "colsum")
+    return db
+
+
+def zero_stuff2(dy: Tensor) -> Tensor:
+    _dev_check(dy, "dy")
+    n, h, w, c = dy.shape
+    z = torch.empty((n, 2 * h, 2 * w, c), dtype=torch.float32, device=dy.device)
+    nat.check(nat.load().virnet_zero_stuff2(nat.ptr(dy), nat.ptr(z), n, h, w, c, nat.stream_handle()), "zero_stuff2")
+    return z
+
+
+def space_to_depth2(dy: Tensor) -> Tensor:
+    _dev_check(dy, "dy")
+    n, h2, w2, c = dy.shape
+    out = torch.empty((n, h2 // 2, w2 // 2, 4 * c), dtype=torch.float32, device=dy.device)
+    nat.check(nat.load().virnet_space_to_depth2(nat.ptr(dy), nat.ptr(out), n, h2 // 2, w2 // 2, c, nat.stream_handle()), "space_to_depth2")
+    return out
+
+
+def pack_input_backward(drec: Tensor, chan: int, hw: Tuple[int, int], *, map_: Optional[Tensor] = None, map_sqrt: bool = False,
+                        into: Optional[Tensor] = None) -> Tensor:
+    """Gradient of one map channel of virnet_pack_input: [N,1,h,w] from the NHWC record gradient (reflect-pad adjoint, sqrt')."""
+    _dev_check(drec, "drec")
+    n, hp, wp, crec = drec.shape
+    h, w = hw
+    out = into if into is not None else torch.empty((n, 1, h, w), dtype=torch.float32, device=drec.device)
+    nat.check(nat.load().virnet_pack_input_backward(nat.ptr(drec), crec, chan, nat.ptr(map_), nat.ptr(out), n, h, w, hp, wp,
+                                                    int(map_sqrt), int(into is not None), nat.stream_handle()), "pack_input_backward")
+    return out
