@@ -147,6 +147,7 @@ typedef struct virnet_pack_desc {
   int ev;
   int em, mh, mw, msf, map_sqrt;
   int hp, wp;
+  int zero_pad;      /* 1: positions beyond h*sf, w*sf are zero instead of reflected (gradient records of the training step) */
 } virnet_pack_desc;
 int virnet_pack_input(const virnet_pack_desc* d, void* stream);
 

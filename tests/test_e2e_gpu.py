@@ -127,8 +127,8 @@ def test_outputs_are_fresh_and_module_api(manifest):
         mu_b, _ = net.train()(x)
         net.eval()
     assert torch.equal(mu_b, keep) and not mu_b.requires_grad
-    mu_c, _ = net(x)          # grad mode on: inference path still returns detached fp32 results
-    assert torch.equal(mu_c, keep)
+    mu_c, _ = net(x)          # grad mode on: same numbers, now recorded for backward (train_denoising_syn.py:176)
+    assert torch.equal(mu_c, keep) and mu_c.requires_grad
     with pytest.raises(ValueError, match="channels"):
         net(torch.zeros(1, 1, 32, 32, device="cuda"))
 

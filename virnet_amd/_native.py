@@ -42,7 +42,7 @@ class PackDesc(C.Structure):
         ("n", C.c_int), ("c0", C.c_int), ("h", C.c_int), ("w", C.c_int), ("sf", C.c_int),
         ("ev", C.c_int),
         ("em", C.c_int), ("mh", C.c_int), ("mw", C.c_int), ("msf", C.c_int), ("map_sqrt", C.c_int),
-        ("hp", C.c_int), ("wp", C.c_int),
+        ("hp", C.c_int), ("wp", C.c_int), ("zero_pad", C.c_int),
     ]
 
 

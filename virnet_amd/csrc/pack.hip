@@ -57,6 +57,7 @@ __global__ void pack_input_kernel(const virnet_pack_desc d) {
     const int y = (int)((pix / d.wp) % d.hp);
     const int n = (int)(pix / ((size_t)d.wp * d.hp));
     const int ry = reflect(y, HU), rx = reflect(x, WU);
+    const bool dead = d.zero_pad && (y >= HU || x >= WU);
     float v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -70,7 +71,7 @@ __global__ void pack_input_kernel(const virnet_pack_desc d) {
         val = d.map[(((size_t)n * d.em + c) * d.mh + ry / d.msf) * d.mw + rx / d.msf];
         if (d.map_sqrt) val = sqrtf(val);
       }
-      v[k] = val;
+      v[k] = dead ? 0.f : val;
     }
     reinterpret_cast<float4*>(d.out)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }

@@ -34,7 +34,13 @@ class VIRAttResUNet(nn.Module):
                                extra_mode=extra_mode)
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """x [N,C,H,W] -> (mu [N,C,H,W], sigma [N,sigma_chn,H,W]); sigma is a variance map (VIRNet.py:42-46)."""
+        """x [N,C,H,W] -> (mu [N,C,H,W], sigma [N,sigma_chn,H,W]); sigma is a variance map (VIRNet.py:42-46).
+
+        With gradients enabled and trainable parameters the call is recorded for ``loss.backward()`` (train_denoising_syn.py:176-179):
+        forward and backward both run on the HIP kernels (virnet_amd/train.py)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .. import train
+            return train.denoise_forward_autograd(self, x)
         return engine.denoise_forward(self, x)
 
     def graphed(self) -> GraphedForward:
@@ -57,7 +63,10 @@ class VIRAttResUNetSR(nn.Module):
                                extra_mode=extra_mode)
 
     def forward(self, x: torch.Tensor, sf: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """x [N,C,h,w], sf -> (mu [N,C,h*sf,w*sf], kinfo [N,kernel_chn], sigma) (VIRNet.py:80-97)."""
+        """x [N,C,h,w], sf -> (mu [N,C,h*sf,w*sf], kinfo [N,kernel_chn], sigma) (VIRNet.py:80-97).  Inference only so far."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("VIRAttResUNetSR: the training step (KNet / SFT backward) is not built on the HIP path yet; "
+                                      "call it under torch.no_grad() for inference")
         return engine.sisr_forward(self, x, sf)
 
     def graphed(self) -> GraphedForward:

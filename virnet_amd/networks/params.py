@@ -45,6 +45,14 @@ class ConvParam(nn.Module):
             self._pack_key = key
         return self._pack
 
+    def packed_dgrad(self) -> ops.PackedWeight:
+        """Packing of this layer's input-gradient GEMM (training step), cached like ``packed``."""
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device))
+        if getattr(self, "_dgrad", None) is None or self._dgrad_key != key:
+            self._dgrad = ops.pack_weight(self.weight, None, transposed=self.transposed, dgrad=True)
+            self._dgrad_key = key
+        return self._dgrad
+
     def packed_thin(self) -> ops.PackedWeight:
         """Packing for the bandwidth-bound few-output-channel kernel (3x3, cout <= 4), cached like ``packed``."""
         key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),

@@ -246,7 +246,7 @@ def conv3x3_thin(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: i
 
 
 def pack_input(x: Tensor, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor] = None,
-               map_: Optional[Tensor] = None, map_sf: int = 1, map_sqrt: bool = False) -> Tensor:
+               map_: Optional[Tensor] = None, map_sf: int = 1, map_sqrt: bool = False, zero_pad: bool = False) -> Tensor:
     """NCHW image (+ per-image vector / per-pixel map) -> [N, hp, wp, 16] NHWC records (up-sample, reflect pad, concat)."""
     _dev_check(x, "x")
     n, c0, h, w = x.shape
@@ -258,7 +258,7 @@ def pack_input(x: Tensor, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor
         _dev_check(map_, "map")
     out = torch.empty((n, hp, wp, 16), dtype=torch.float32, device=x.device)
     d = nat.PackDesc(x=nat.ptr(x), vec=nat.ptr(vec), map=nat.ptr(map_), out=nat.ptr(out), n=n, c0=c0, h=h, w=w, sf=sf,
-                     ev=ev, em=em, mh=mh, mw=mw, msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp)
+                     ev=ev, em=em, mh=mh, mw=mw, msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp, zero_pad=int(zero_pad))
     nat.check(nat.load().virnet_pack_input(C.byref(d), nat.stream_handle()), "pack_input")
     return out
 

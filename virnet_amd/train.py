@@ -1,0 +1,181 @@
+"""Training step of the denoiser on the HIP path (reference train_denoising_syn.py:176-184).
+
+``VIRAttResUNet.forward`` routes here when gradients are enabled and a parameter requires them: the whole network is ONE
+``torch.autograd.Function`` whose forward is the same kernel sequence as inference (keeping the tensors the backward needs) and
+whose backward walks the layers in reverse with hand-written kernels only:
+
+  * input gradients  : ``virnet_conv_mfma`` with the layer's dgrad packing (flipped/transposed 3x3 taps; the stride-2 conv on the
+    zero-stuffed gradient; the transposed conv as a pointwise GEMM over the space-to-depth gradient), the LeakyReLU derivative and
+    the residual / bridge gradient fused into the epilogue (``mask``, ``res``);
+  * weight gradients : ``virnet_conv_wgrad`` (MFMA, contraction over pixels) with the forward conv's staging transform;
+  * bias gradients   : ``virnet_colsum``.
+
+The ELBO itself (loss/ELBO_simple.py) stays host-side PyTorch on ``mu`` and ``sigma`` as BASELINE.json's north_star asks; autograd
+hands its gradients to ``backward`` below.  fp32 throughout.  SISR training (KNet / SFT backward) is not built yet.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from . import ops
+from .engine import LOG_MAX, LOG_MIN, _ceil_to, _prep
+
+Tensor = torch.Tensor
+
+
+class _Tape:
+    """What the backward needs, in forward order."""
+
+    def __init__(self):
+        self.snet: dict = {}
+        self.blocks: List[dict] = []        # residual blocks in execution order
+        self.misc: dict = {}
+
+
+def _thin(conv, x, crop, **kw):
+    return ops.conv3x3_thin(x, conv.packed_thin(), crop, **kw) if conv.cout <= 4 else ops.conv_mfma_nchw(x, conv.packed(), crop, **kw)
+
+
+def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
+    snet, rnet = net.SNet, net.RNet
+    if snet.noise_avg:
+        raise NotImplementedError("training path: noise_avg=True (pooled variance) is not built")
+    if rnet.extra_mode not in ("input", "null"):
+        raise NotImplementedError("training path: SFT conditioning (extra_mode down/both) is not built yet")
+    x = _prep(x, snet.in_channels)
+    n, _, h, w = x.shape
+    tape = _Tape()
+    # ---- SNet (networks/DnCNN.py:37-44)
+    rec_s = ops.pack_input(x, h, w)
+    acts = []
+    _, cur = ops.conv_mfma(rec_s, snet.conv1.packed(), want_raw=False, want_act=True, slope=0.25)
+    acts.append(cur)
+    mids = [snet.mid_layer[k] for k in sorted(snet.mid_layer.keys(), key=int)]
+    for conv in mids:
+        _, cur = ops.conv_mfma(cur, conv.packed(), want_raw=False, want_act=True, slope=0.25)
+        acts.append(cur)
+    sigma = _thin(snet.conv_last, cur, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(LOG_MIN, LOG_MAX))
+    tape.snet = dict(rec=rec_s, acts=acts, mids=mids, sigma=sigma)
+    # ---- RNet (networks/AttResUNet.py:141-175)
+    m = 1 << (rnet.depth - 1)
+    hp, wp = _ceil_to(h, m), _ceil_to(w, m)
+    cond = net.noise_cond and rnet.extra_mode == "input"
+    rec = ops.pack_input(x, hp, wp, map_=sigma if cond else None, map_sqrt=True)
+    xcur, _ = ops.conv_mfma(rec, rnet.head.packed(), want_raw=True)
+    bridges = []
+    order = []                                            # ("block", blk, x_in, f1a) / ("down", conv, x_in) / ("up", conv, x_in)
+    for ii, lvl in enumerate(rnet.down_path):
+        for blk in lvl.body:
+            _, f1a = ops.conv_mfma(xcur, blk.conv1.packed(), in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
+            out, _ = ops.conv_mfma(f1a, blk.conv2.packed(), res=xcur, want_raw=True)
+            order.append(("block", blk, xcur, f1a))
+            xcur = out
+        if ii + 1 < len(rnet.down_path):
+            bridges.append(xcur)
+            out, _ = ops.conv_mfma(xcur, lvl.downsampler.packed(), stride=2, want_raw=True)
+            order.append(("down", lvl.downsampler, xcur, None))
+            xcur = out
+    for jj, up in enumerate(rnet.up_path):
+        out, _ = ops.conv_mfma(xcur, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True)
+        order.append(("up", up.upsampler, xcur, len(bridges) - 1 - jj))
+        xcur = out
+        for blk in up.body:
+            _, f1a = ops.conv_mfma(xcur, blk.conv1.packed(), in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
+            out, _ = ops.conv_mfma(f1a, blk.conv2.packed(), res=xcur, want_raw=True)
+            order.append(("block", blk, xcur, f1a))
+            xcur = out
+    mu = _thin(rnet.tail, xcur, (h, w), op=nat.NCHW_ADD, res=x)
+    tape.misc = dict(rec=rec, x_last=xcur, order=order, nbridges=len(bridges), hw=(h, w), hpwp=(hp, wp), cond=cond)
+    return mu, sigma, tape
+
+
+def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1, in_slope: Optional[float] = None,
+                cvalid: Optional[int] = None) -> None:
+    """dW, db of one conv from its forward input and output gradient (NHWC)."""
+    grads[conv.weight] = ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)
+    if conv.bias is not None:
+        grads[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+
+
+def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[Tensor]) -> Dict:
+    snet, rnet = net.SNet, net.RNet
+    grads: Dict = {}
+    h, w = tape.misc["hw"]
+    hp, wp = tape.misc["hpwp"]
+    sigma = tape.snet["sigma"]
+    n = sigma.shape[0]
+    d_sigma_total = torch.zeros_like(sigma) if dsigma is None else dsigma.detach().contiguous().clone()
+    if dmu is not None:
+        dmu = dmu.detach().contiguous()
+        # ---- tail: mu = conv(x_last)[crop] + x_in  (AttResUNet.py:173)
+        g16 = ops.pack_input(dmu, hp, wp, zero_pad=True)                       # gradient record, zero beyond the crop
+        _conv_grads(grads, rnet.tail, tape.misc["x_last"], g16)
+        dx, _ = ops.conv_mfma(g16, rnet.tail.packed_dgrad(), want_raw=True)
+        nb = tape.misc["nbridges"]
+        dbridge: List[Optional[Tensor]] = [None] * nb
+        for kind, mod, x_in, aux in reversed(tape.misc["order"]):
+            if kind == "block":                                                 # AttResBlock, AttResUNet.py:48-60
+                f1a = aux
+                _conv_grads(grads, mod.conv2, f1a, dx)
+                d_f1, _ = ops.conv_mfma(dx, mod.conv2.packed_dgrad(), mask=f1a, mask_slope=0.2, want_raw=True)
+                _conv_grads(grads, mod.conv1, x_in, d_f1, in_slope=0.2)
+                dx, _ = ops.conv_mfma(d_f1, mod.conv1.packed_dgrad(), mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
+            elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
+                dbridge[aux] = dx
+                s2d = ops.space_to_depth2(dx)
+                grads[mod.weight] = ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True)
+                grads[mod.bias] = ops.colsum(dx)
+                dx, _ = ops.conv_mfma(s2d, mod.packed_dgrad(), want_raw=True)
+            else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
+                _conv_grads(grads, mod, x_in, dx, stride=2)
+                nb -= 1
+                dx, _ = ops.conv_mfma(ops.zero_stuff2(dx), mod.packed_dgrad(), res=dbridge[nb], want_raw=True)
+        # ---- head (AttResUNet.py:153-155): weights, and the gradient flowing into sqrt(sigma) through the conditioning channel
+        rec = tape.misc["rec"]
+        _conv_grads(grads, rnet.head, rec, dx)
+        if tape.misc["cond"]:
+            drec, _ = ops.conv_mfma(dx, rnet.head.packed_dgrad(), want_raw=True, out_channels=32)
+            parts = [ops.pack_input_backward(drec, rnet.in_chn + c, (h, w), map_=sigma[:, c:c + 1].contiguous(), map_sqrt=True)
+                     for c in range(sigma.shape[1])]
+            d_sigma_total += torch.cat(parts, 1)
+    else:
+        for p in rnet.parameters():
+            grads[p] = torch.zeros_like(p)
+    # ---- SNet: sigma = exp(clamp(v))  (VIRNet.py:43) -> dv = dsigma * sigma inside the clamp range
+    inside = (sigma > float(torch.tensor(LOG_MIN).exp())) & (sigma < float(torch.tensor(LOG_MAX).exp()))
+    dv = (d_sigma_total * sigma * inside).contiguous()                           # few-channel map: host-side glue
+    g16 = ops.pack_input(dv, h, w, zero_pad=True)
+    acts, mids = tape.snet["acts"], tape.snet["mids"]
+    _conv_grads(grads, snet.conv_last, acts[-1], g16)
+    dpre, _ = ops.conv_mfma(g16, snet.conv_last.packed_dgrad(), mask=acts[-1], mask_slope=0.25, want_raw=True)
+    for k in range(len(mids) - 1, -1, -1):                                       # post-activation stack, DnCNN.py:25-28
+        _conv_grads(grads, mids[k], acts[k], dpre)
+        dpre, _ = ops.conv_mfma(dpre, mids[k].packed_dgrad(), mask=acts[k], mask_slope=0.25, want_raw=True)
+    _conv_grads(grads, snet.conv1, tape.snet["rec"], dpre)
+    return grads
+
+
+class DenoiseFunction(torch.autograd.Function):
+    """mu, sigma = f(x; parameters): forward and backward both run on the C-ABI kernels."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        with torch.no_grad():
+            mu, sigma, tape = denoise_forward_train(net, x)
+        ctx.net, ctx.tape, ctx.params = net, tape, params
+        return mu, sigma
+
+    @staticmethod
+    def backward(ctx, dmu, dsigma):
+        with torch.no_grad():
+            grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma)
+        ctx.tape = None
+        return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
+
+
+def denoise_forward_autograd(net, x: Tensor) -> Tuple[Tensor, Tensor]:
+    params = tuple(net.parameters())
+    return DenoiseFunction.apply(x, net, *params)
