@@ -104,15 +104,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256, help="image height=width")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 @256, 64 @128)")
-    ap.add_argument("--task", default="denoise", choices=["denoise", "sisr"],
-                    help="sisr = BASELINE configs[3]: VIRAttResUNetSR x4 on LR 64x64 (-> 256x256), 16 images per GPU")
+    ap.add_argument("--task", default="denoise", choices=["denoise", "sisr", "train"],
+                    help="sisr = BASELINE configs[3]: VIRAttResUNetSR x4 on LR 64x64 (-> 256x256), 16 images per GPU; "
+                         "train = configs[4]: denoise-syn forward + ELBO + backward (+Adam with --optimizer) on 128x128, 32 per GPU, fp32")
+    ap.add_argument("--optimizer", action="store_true", help="train task: include grad clipping + Adam step in the timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     sisr = args.task == "sisr"
+    training = args.task == "train"
     if sisr and args.size == 256:
         args.size = 64                      # LR size; the output is 4x
-    batch = args.batch if args.batch is not None else (16 if sisr else (32 if args.size >= 256 else 64))
+    if training and args.size == 256:
+        args.size = 128                     # configs/denoising_syn.json:6 patch_size
+    batch = args.batch if args.batch is not None else (16 if sisr else 32 if (training or args.size >= 256) else 64)
 
     rank, local_rank, world = vdist.init()
     if world != args.gpus:
@@ -122,7 +127,7 @@ def main():
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (modulo: lets a 1-GPU box rehearse N ranks over gloo)
     torch.cuda.set_device(dev)
 
-    net, sd = build_net(dev, args.task)
+    net, sd = build_net(dev, "sisr" if sisr else "denoise")
     fwd = (lambda t: net(t, 4)) if sisr else net
     if rank == 0:
         net.load_state_dict(sd, strict=True)       # other ranks keep their random init until the broadcast
@@ -140,7 +145,34 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    with torch.no_grad():
+    if training:
+        # one step of train_denoising_syn.py:171-184 on resident synthetic data: forward, ELBO (host-side PyTorch,
+        # loss/ELBO_simple.py:23-53), backward through the HIP kernels, optionally clip + Adam
+        import math
+        net.train()
+        gt = synth_images(b - a, 3, args.size, args.size, seed=7 + rank).to(dev)
+        sigma_gt = (0.02 + 0.25 * synth_images(b - a, 1, args.size, args.size, seed=11 + rank).to(dev)) ** 2
+        alpha0 = torch.tensor([0.5 * 7 ** 2], dtype=torch.float32, device=dev)      # var_window 7 (configs/denoising_syn.json:38)
+        beta0, eps2 = alpha0 * sigma_gt, 1e-6
+        opt = torch.optim.Adam(net.parameters(), lr=2e-4) if args.optimizer else None
+        p_r = [p for n_, p in net.named_parameters() if "rnet" in n_.lower()]
+        p_s = [p for n_, p in net.named_parameters() if "snet" in n_.lower()]
+
+        def fwd(t):
+            for p in net.parameters():
+                p.grad = None
+            mu_, sig_ = net(t)
+            beta, ap = sig_ * alpha0, alpha0 - 1
+            loss = (0.5 * (beta.log() - torch.digamma(ap) + ap / beta * ((t - mu_) ** 2 + eps2)) + 0.5 * math.log(2 * math.pi)).mean() \
+                + 0.5 * ((mu_ - gt) ** 2 / eps2).mean() + (ap * (beta0 / beta - 1) + ap * (beta.log() - beta0.log())).mean()
+            loss.backward()
+            if opt is not None:
+                torch.nn.utils.clip_grad_norm_(p_r, 1e3)
+                torch.nn.utils.clip_grad_norm_(p_s, 1e2)
+                opt.step()
+            return (mu_.detach(),)
+
+    with torch.set_grad_enabled(training):
         for _ in range(args.warmup):
             fwd(x)
         timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
@@ -160,21 +192,21 @@ def main():
     roof = None
     if timer is not None:
         summ = timer.summary()
-        cands = [k for k in summ if k[0] == 3 and k[1] == 1]
+        cands = [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3] or [k for k in summ if k[0] == 3 and k[1] == 1]
         dom = max(cands, key=lambda k: summ[k]["ms"]) if cands else None
         d = summ.get(dom)
         if d:
             avg_ms = d["ms"] / d["launches"]
             achieved = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in summ.values())
-            pmc = load_pmc_traffic() if (not sisr and args.size == 256 and batch == 32) else None   # measured on this workload only
+            pmc = load_pmc_traffic() if (not sisr and not training and args.size == 256 and batch == 32) else None   # measured on this workload only
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch"),
                     "kernel": "conv_mfma_kernel<%d,%d,%d,%d>" % dom, "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC, algorithmic)", "share_of_conv_time": round(d["ms"] / total_ms, 4),
-                    "by_kernel_ms_per_step": {("conv3x3_thin<cout=%d>" % k[3] if k[0] == "thin" else "conv_mfma<%d,%d,%d,%d>" % k):
+                    "by_kernel_ms_per_step": {("conv3x3_thin<cout=%d>" % k[3] if k[0] == "thin" else "conv_wgrad<ks=%d,s=%d,t=%d>" % k[1:] if k[0] == "wgrad" else "conv_mfma<%d,%d,%d,%d>" % k):
                                               round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))}}
     if world > 1:
         torch.distributed.barrier()
@@ -184,8 +216,11 @@ def main():
         value = imgs / elapsed
         hp = (args.size + 3) // 4 * 4
         gflop_img = SISR_GFLOP_PER_IMAGE * (args.size / 64.0) ** 2 if sisr else KFLOP_PER_PIXEL * hp * hp / 1e6
+        if training:
+            gflop_img *= 3.0                  # forward + input-gradient + weight-gradient convs (~3x forward)
         out = {
-            "metric": (f"images/sec (SISR x4 fwd, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if sisr else
+            "metric": (f"images/sec (denoise-syn training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, {args.size}x{args.size}x3)" if training else
+                       f"images/sec (SISR x4 fwd, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if sisr else
                        "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -198,7 +233,7 @@ def main():
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or sisr) else cpu_baseline(sd, args.size),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or sisr or training) else cpu_baseline(sd, args.size),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

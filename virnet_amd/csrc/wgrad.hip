@@ -14,6 +14,7 @@
 // the tensor are zero-filled; the same pre-activation as the forward conv (lrelu(x*mul+add)) is applied to A on the way in.
 #include "common.h"
 #include "../../include/virnet_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -144,25 +145,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WArgs a) {
     __syncthreads();
   }
 
-  // ---- partial sums -> dW (fp32 atomics).  Lane: column ci = cib*32 + l31, rows co = cob*32 + (r&3) + 8*(r>>2) + 4*lhi.
-  const int ci = cib * 32 + l31;
-  if (ci < a.cin) {
+  // ---- partial sums -> dW.  The four waves hold partials of the SAME (co, ci, tap) entries (different rows of the tiles):
+  // reduce them through LDS, tap by tap, then ONE fp32 atomic per entry per workgroup.
+  // Accumulator element (r, lane): row co = cob*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), column ci = cib*32 + (lane&31).
+  float* const red = xs;                             // 4 waves x 16 x 64 floats = 16 KB (<= the pixel tile)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (co >= a.cout) continue;
+  for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
-      for (int t = 0; t < NTAPS; ++t) {
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 1024; e += 256) {
+      const int r = e >> 6, ln = e & 63;
+      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      const int ci = cib * 32 + (ln & 31);
+      if (co < a.cout && ci < a.cin) {
         size_t o;
-        if (a.transposed) {                       // row co = ab*cout_t + c  ->  dw[ci][c][a][b]
+        if (a.transposed) {                          // row co = ab*cout_t + c  ->  dw[ci][c][a][b]
           const int ab = co / a.cout_t, c = co - ab * a.cout_t;
           o = ((size_t)ci * a.cout_t + c) * 4 + ab;
         } else {
           o = ((size_t)co * a.cin + ci) * NTAPS + t;
         }
-        atomicAdd(a.dw + o, acc[t][r]);
+        atomicAdd(a.dw + o, v);
       }
     }
+    __syncthreads();
   }
 }
 
@@ -205,7 +214,8 @@ int launch_wgrad(WArgs k, hipStream_t st) {
   k.nty = (k.oh + 3) / 4;
   k.ntiles = k.n * k.nty * k.ntx;
   const int pairs = k.ncob * k.ncib;
-  int split = (1024 + pairs - 1) / pairs;                   // ~4 workgroups per CU in total
+  static const int target = [] { const char* e = getenv("VIRNET_WGRAD_WGS"); return e ? atoi(e) : 1024; }();   // tuning knob
+  int split = (target + pairs - 1) / pairs;                 // ~4 workgroups per CU in total
   if (split > k.ntiles) split = k.ntiles;
   if (split < 1) split = 1;
   hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, TW>), dim3(pairs, split), dim3(256), 0, st, k);

@@ -374,7 +374,15 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw), n=n, h=h, w=w,
                       cx=cx, cy=cy, cin=cin, cout=cout, ks=ks, stride=stride, transposed=int(transposed),
                       in_act=int(in_slope is not None), in_slope=0.0 if in_slope is None else in_slope)
-    nat.check(nat.load().virnet_conv_wgrad(C.byref(d), nat.stream_handle()), "conv_wgrad")
+    if _TIMER is None:
+        nat.check(nat.load().virnet_conv_wgrad(C.byref(d), nat.stream_handle()), "conv_wgrad")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.check(nat.load().virnet_conv_wgrad(C.byref(d), nat.stream_handle()), "conv_wgrad")
+        e1.record()
+        pix = n * (h // stride) * (w // stride)
+        _TIMER.records.append((("wgrad", ks, stride, int(transposed)), 2.0 * pix * cin * cout * (4 if transposed else ks * ks), e0, e1))
     return dw
 
 
