@@ -148,7 +148,6 @@ def main():
     if training:
         # one step of train_denoising_syn.py:171-184 on resident synthetic data: forward, ELBO (host-side PyTorch,
         # loss/ELBO_simple.py:23-53), backward through the HIP kernels, optionally clip + Adam
-        import math
         net.train()
         gt = synth_images(b - a, 3, args.size, args.size, seed=7 + rank).to(dev)
         sigma_gt = (0.02 + 0.25 * synth_images(b - a, 1, args.size, args.size, seed=11 + rank).to(dev)) ** 2
@@ -158,13 +157,13 @@ def main():
         p_r = [p for n_, p in net.named_parameters() if "rnet" in n_.lower()]
         p_s = [p for n_, p in net.named_parameters() if "snet" in n_.lower()]
 
+        from virnet_amd.loss import elbo_denoising_simple
+
         def fwd(t):
             for p in net.parameters():
                 p.grad = None
             mu_, sig_ = net(t)
-            beta, ap = sig_ * alpha0, alpha0 - 1
-            loss = (0.5 * (beta.log() - torch.digamma(ap) + ap / beta * ((t - mu_) ** 2 + eps2)) + 0.5 * math.log(2 * math.pi)).mean() \
-                + 0.5 * ((mu_ - gt) ** 2 / eps2).mean() + (ap * (beta0 / beta - 1) + ap * (beta.log() - beta0.log())).mean()
+            loss = elbo_denoising_simple(mu_, sig_, t, gt, eps2, alpha0, beta0)[0]
             loss.backward()
             if opt is not None:
                 torch.nn.utils.clip_grad_norm_(p_r, 1e3)

@@ -123,16 +123,11 @@ def test_pack_input_backward_is_the_adjoint():
 
 
 def _elbo(mu, sigma, im_noisy, im_gt, sigma_gt, eps2=1e-6, var_window=7):
-    """loss/ELBO_simple.py:12-53 restated for the test (alpha0 = 0.5*var_window**2, train_denoising_syn.py:157,172)."""
-    import math
-    alpha0 = torch.tensor([0.5 * var_window ** 2], dtype=torch.float32, device=mu.device)
-    beta0 = alpha0 * sigma_gt
-    kl_gauss = 0.5 * ((mu - im_gt) ** 2 / eps2).mean()
-    beta = sigma * alpha0
-    ap = alpha0 - 1
-    kl_ig = (ap * (beta0 / beta - 1) + ap * (beta.log() - beta0.log())).mean()
-    lh = (0.5 * (beta.log() - torch.digamma(ap) + ap / beta * ((im_noisy - mu) ** 2 + eps2)) + 0.5 * math.log(2 * math.pi)).mean()
-    return lh + kl_gauss + kl_ig
+    """The training loss exactly as train_denoising_syn.py:157,172,177 assembles it (virnet_amd/loss.py is pinned to the
+    reference's loss/ELBO_simple.py by tests/test_loss.py)."""
+    from virnet_amd.loss import elbo_denoising_simple
+    alpha0 = torch.tensor([0.5 * var_window ** 2], dtype=mu.dtype, device=mu.device)
+    return elbo_denoising_simple(mu, sigma, im_noisy, im_gt, eps2, alpha0, alpha0 * sigma_gt)[0]
 
 
 @pytest.mark.parametrize("cfg,shape", [
