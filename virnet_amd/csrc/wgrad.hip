@@ -5,7 +5,8 @@
 // is a GEMM whose contraction runs over PIXELS: D[co][ci] += dY^T[co][p] * A[p][ci], once per tap.  On the matrix cores
 // (v_mfma_f32_32x32x2_f32, exact fp32) one instruction contracts 2 pixels for a 32x32 (co, ci) block, so a wave keeps ALL taps
 // of one (co-block, ci-block) pair in registers (KS*KS accumulator blocks) and per 2-pixel step reads ONE dY fragment and KS*KS
-// shifted A fragments from LDS (ds_read_b32, one channel per lane -> conflict free).
+// shifted A fragments from LDS (ds_read_b32, one channel per lane -> conflict free); the 3x3 stride-1 case pairs two ROWS per
+// MFMA and slides a 3x3 register window along the columns, so only 1 + 3 fragments are read per 9 MFMAs.
 //
 // Workgroup = 4 waves = 4 output rows x TW columns of one (co-block, ci-block) pair; it walks a strided list of such tiles
 // (split-K over the image set) accumulating in registers, then adds its partial sums into dW with fp32 atomics (dW is
@@ -126,6 +127,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WArgs a) {
     const int nxt = tile + gridDim.y;
     if (nxt < a.ntiles) fetch(nxt);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KS == 3 && STRIDE == 1) {
+      // Row-pair contraction with a sliding register window: the two pixels an MFMA contracts are (row, col) for lanes 0-31 and
+      // (row+1, col) for lanes 32-63, so the nine taps of column c are the 3x3 window x[row+dy][c+dx] in BOTH halves; stepping
+      // to column c+1 re-uses six of the nine fragments from registers: 1 dY + 3 new x fragments per 9 MFMAs (instead of 1 + 9).
+      // Wave w: row pair (w&1), column half (w>>1) of the 4x32 tile.
+      const int r0 = 2 * (wave & 1) + lhi, cbeg = (TW / 2) * (wave >> 1);
+      const float* const xrow = xs + (r0 * IW + cbeg) * 32 + l31;
+      const float* const yrow = ys + (r0 * TW + cbeg) * 32 + l31;
+      float xw[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        xw[dy][0] = xrow[(dy * IW + 0) * 32];
+        xw[dy][1] = xrow[(dy * IW + 1) * 32];
+      }
+#pragma unroll
+      for (int c = 0; c < TW / 2; ++c) {
+        const float yv = yrow[c * 32];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) xw[dy][2] = xrow[(dy * IW + c + 2) * 32];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            acc[dy * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, xw[dy][dx], acc[dy * 3 + dx], 0, 0, 0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) { xw[dy][0] = xw[dy][1]; xw[dy][1] = xw[dy][2]; }
+      }
+    } else {
     // this wave's row: TW/2 two-pixel steps
 #pragma unroll 4
     for (int s = 0; s < TW / 2; ++s) {
@@ -138,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WArgs a) {
       }
 #pragma unroll
       for (int t = 0; t < NTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, xv[t], acc[t], 0, 0, 0);
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
