@@ -161,6 +161,7 @@ typedef struct virnet_wgrad_desc {
   const float* in_mul;  /* the forward conv's staging transform (lrelu(x*in_mul+in_add)), or NULL */
   const float* in_add;
   float* dw;            /* += : [cout][cin][ks][ks] (OIHW) or, transposed, [cin][cout][2][2]; zero it first (fp32 atomics) */
+  int* counters;        /* zeroed int32 scratch, ceil(rows/32)*ceil(cin/32) entries (rows = cout, or 4*cout transposed): tile hand-out */
   int n, h, w, cx, cy;
   int cin, cout;        /* real channel counts (<= cx, cy) */
   int ks, stride;       /* {3,1} {3,2} {1,1} */

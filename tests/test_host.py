@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_struct_sizes_match_header_layout():
     # pointer-first structs: 8 pointers + ints/floats, no hidden padding surprises
     assert ctypes.sizeof(_native.ConvDesc) == 11 * 8 + 15 * 4 + 5 * 4  # 11 pointers, 15 ints, 5 floats
-    assert ctypes.sizeof(_native.WgradDesc) == 5 * 8 + 11 * 4 + 4 + 0
+    assert ctypes.sizeof(_native.WgradDesc) == 6 * 8 + 11 * 4 + 4 + 0
     assert ctypes.sizeof(_native.PackDesc) == 4 * 8 + 14 * 4
     assert ctypes.sizeof(_native.SftWeights) == 8 * 8 + 4 * 4
     assert ctypes.sizeof(_native.ConvPlan) == 12

@@ -58,7 +58,7 @@ class ThinDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("dy", C.c_void_p), ("in_mul", C.c_void_p), ("in_add", C.c_void_p), ("dw", C.c_void_p),
-        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cx", C.c_int), ("cy", C.c_int),
+        ("counters", C.c_void_p), ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("cx", C.c_int), ("cy", C.c_int),
         ("cin", C.c_int), ("cout", C.c_int), ("ks", C.c_int), ("stride", C.c_int), ("transposed", C.c_int),
         ("in_act", C.c_int), ("in_slope", C.c_float),
     ]

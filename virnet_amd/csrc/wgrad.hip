@@ -28,6 +28,7 @@ struct WArgs {
   const float* in_mul;  // [n][cx] or null
   const float* in_add;
   float* dw;            // [cout][cin][ks][ks] (conv) or [cin][cout][2][2] (transposed conv), += with atomics
+  int* ctr;             // [ncob*ncib] zero-initialised tile counters (dynamic tile hand-out per channel-block pair)
   int n, h, w, cx, oh, ow, cy;
   int cin, cout;        // real channel counts of dw (rows of dy used: cout, channels of x used: cin)
   int ncob, ncib;       // 32-channel blocks
@@ -117,14 +118,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  int tile = blockIdx.y;
+  // Tiles are handed out dynamically: the workgroups of one (co, ci) pair draw tile indices from a shared counter, so a slow
+  // workgroup takes fewer tiles instead of holding up the launch (static shares left 1.67 of 2 waves per SIMD resident).
+  // Thread 0 draws the index two tiles ahead; it travels through LDS across the barriers the tile loop already has.
+  __shared__ int tsel[2];
+  int* const ctr = a.ctr + blk;
+  if (tid == 0) {
+    tsel[0] = atomicAdd(ctr, 1);
+    tsel[1] = atomicAdd(ctr, 1);
+  }
+  __syncthreads();
+  int tile = tsel[0], nxt = tsel[1];
   if (tile < a.ntiles) {
     fetch(tile);
     land();
   }
   __syncthreads();
-  for (; tile < a.ntiles; tile += gridDim.y) {
-    const int nxt = tile + gridDim.y;
+  while (tile < a.ntiles) {
+    int drawn = 0;
+    if (tid == 0) drawn = atomicAdd(ctr, 1);                    // the tile after next; its value is only needed after the MFMAs
     if (nxt < a.ntiles) fetch(nxt);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (KS == 3 && STRIDE == 1) {
@@ -170,9 +182,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WArgs a) {
     }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (tid == 0) tsel[0] = drawn;
     __syncthreads();
     if (nxt < a.ntiles) land();
+    const int nn = tsel[0];
     __syncthreads();
+    tile = nxt;
+    nxt = nn;
   }
 
   // ---- partial sums -> dW.  The four waves hold partials of the SAME (co, ci, tap) entries (different rows of the tiles):
@@ -244,8 +260,18 @@ int launch_wgrad(WArgs k, hipStream_t st) {
   k.nty = (k.oh + 3) / 4;
   k.ntiles = k.n * k.nty * k.ntx;
   const int pairs = k.ncob * k.ncib;
-  static const int target = [] { const char* e = getenv("VIRNET_WGRAD_WGS"); return e ? atoi(e) : 1024; }();   // tuning knob
-  int split = (target + pairs - 1) / pairs;                 // ~4 workgroups per CU in total
+  // Split-K factor: fill the chip exactly ONCE.  Every workgroup runs for the whole launch (its share of the tiles), so a grid
+  // that is not a whole number of residency rounds leaves SIMD slots empty (r01 PMC: 1.50 of 2 resident waves per SIMD with a
+  // 2.004-round grid).  Residency comes from the occupancy query (VGPR/LDS-limited, 2 workgroups per CU here).
+  static int wg_per_cu = 0;
+  if (!wg_per_cu) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, reinterpret_cast<const void*>(conv_wgrad_kernel<KS, STRIDE, TW>), 256, 0) !=
+            hipSuccess || wg_per_cu < 1)
+      wg_per_cu = 1;
+  }
+  static const int forced = [] { const char* e = getenv("VIRNET_WGRAD_WGS"); return e ? atoi(e) : 0; }();   // tuning knob
+  const int slots = forced > 0 ? forced : 256 * wg_per_cu;
+  int split = slots / pairs;
   if (split > k.ntiles) split = k.ntiles;
   if (split < 1) split = 1;
   hipLaunchKernelGGL((conv_wgrad_kernel<KS, STRIDE, TW>), dim3(pairs, split), dim3(256), 0, st, k);
@@ -255,7 +281,7 @@ int launch_wgrad(WArgs k, hipStream_t st) {
 }  // namespace
 
 extern "C" int virnet_conv_wgrad(const virnet_wgrad_desc* d, void* stream) {
-  VIRNET_REQUIRE(d && d->x && d->dy && d->dw, "virnet_conv_wgrad: NULL pointer");
+  VIRNET_REQUIRE(d && d->x && d->dy && d->dw && d->counters, "virnet_conv_wgrad: NULL pointer");
   VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_wgrad: empty input");
   VIRNET_REQUIRE(d->cx > 0 && d->cx % 4 == 0 && d->cy > 0 && d->cy % 4 == 0, "virnet_conv_wgrad: stored channel counts cx=%d cy=%d must be multiples of 4", d->cx, d->cy);
   VIRNET_REQUIRE(d->cin >= 1 && d->cin <= d->cx, "virnet_conv_wgrad: cin=%d > stored %d", d->cin, d->cx);
@@ -264,7 +290,7 @@ extern "C" int virnet_conv_wgrad(const virnet_wgrad_desc* d, void* stream) {
   VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_wgrad: in_mul and in_add go together");
   VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_wgrad: in_slope=%g outside [0,1]", d->in_slope);
   WArgs k{};
-  k.x = d->x; k.dy = d->dy; k.in_mul = d->in_mul; k.in_add = d->in_add; k.dw = d->dw;
+  k.x = d->x; k.dy = d->dy; k.in_mul = d->in_mul; k.in_add = d->in_add; k.dw = d->dw; k.ctr = d->counters;
   k.n = d->n; k.h = d->h; k.w = d->w; k.cx = d->cx; k.cy = d->cy; k.cin = d->cin;
   k.in_act = d->in_act; k.in_slope = d->in_slope;
   if (d->stride == 2) {

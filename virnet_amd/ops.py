@@ -371,7 +371,10 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     else:
         cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
     dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
-    d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw), n=n, h=h, w=w,
+    rows = 4 * cout if transposed else cout
+    ctr = torch.zeros(((rows + 31) // 32) * ((cin + 31) // 32), dtype=torch.int32, device=x.device)
+    d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw),
+                      counters=nat.ptr(ctr), n=n, h=h, w=w,
                       cx=cx, cy=cy, cin=cin, cout=cout, ks=ks, stride=stride, transposed=int(transposed),
                       in_act=int(in_slope is not None), in_slope=0.0 if in_slope is None else in_slope)
     if _TIMER is None:
