@@ -16,6 +16,16 @@ inline int check_launch(const char* what) {
   return 0;
 }
 
+// Per-device "already configured" flag for a kernel's function attributes (a process may drive several GPUs in turn).
+inline bool first_use_on_device(unsigned long long& mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 }  // namespace virnet
 
 #define VIRNET_REQUIRE(cond, ...)                         \

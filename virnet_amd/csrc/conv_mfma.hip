@@ -395,12 +395,11 @@ int launch(const KArgs& ka, hipStream_t st) {
   constexpr int TH = NW * MREP;
   constexpr int IH = (TH - 1) * STRIDE + KS, IW = 31 * STRIDE + KS;
   constexpr int LDS = 2 * IH * IW * 64 + 3 * NREP * 2048;
-  static bool attr_done = false;
+  static unsigned long long attr_done = 0;     // one bit per device
   auto kern = conv_mfma_kernel<KS, STRIDE, MREP, NREP, NW>;
-  if (!attr_done) {
+  if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_mfma): %s", hipGetErrorString(e));
-    attr_done = true;
   }
   KArgs k = ka;
   k.nty = (k.OH + TH - 1) / TH;

@@ -230,12 +230,11 @@ extern "C" int virnet_conv_head_s4(const float* x, const float* w, float* out, i
   const int K = cin * 81;
   const size_t lds = (size_t)K * 65 * sizeof(float);
   VIRNET_REQUIRE(lds <= 160 * 1024, "virnet_conv_head_s4: cin=%d too large for the LDS weight tile", cin);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;     // one bit per device
+  if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_head_s4_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_head_s4): %s", hipGetErrorString(e));
-    attr_done = true;
   }
   const int oh = (h - 1) / 4 + 1, ow = (w_ - 1) / 4 + 1;
   const long npix = (long)n * oh * ow;

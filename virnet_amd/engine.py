@@ -170,6 +170,11 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
 # ----------------------------------------------------------------------------------------------------------------
 def denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
     x = _prep(x, net.SNet.in_channels)
+    with torch.cuda.device(x.device):       # launches go to x's device even when it is not the process's current one
+        return _denoise_forward(net, x)
+
+
+def _denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
     sigma = snet_forward(net.SNet, x, mode="sigma")
     if net.noise_cond:
         if net.SNet.noise_avg:
@@ -184,6 +189,11 @@ def denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
 
 def sisr_forward(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     x = _prep(x, net.SNet.in_channels)
+    with torch.cuda.device(x.device):
+        return _sisr_forward(net, x, sf)
+
+
+def _sisr_forward(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     if int(sf) != sf or sf < 1:
         raise ValueError(f"sf must be a positive integer, got {sf}")
     sf = int(sf)

@@ -163,14 +163,16 @@ class DenoiseFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, *params):
-        with torch.no_grad():
+        x = _prep(x, net.SNet.in_channels)          # raises on CPU / wrong dtype before anything touches a device
+        with torch.no_grad(), torch.cuda.device(x.device):
             mu, sigma, tape = denoise_forward_train(net, x)
         ctx.net, ctx.tape, ctx.params = net, tape, params
         return mu, sigma
 
     @staticmethod
     def backward(ctx, dmu, dsigma):
-        with torch.no_grad():
+        dev = (dmu if dmu is not None else dsigma).device
+        with torch.no_grad(), torch.cuda.device(dev):
             grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma)
         ctx.tape = None
         return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
