@@ -165,3 +165,40 @@ def test_graph_replay_matches_eager(manifest):
         e = snet(x, 2)
         r = gs(x, 2)
     assert all(torch.equal(a, b) for a, b in zip(e, r))
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4, 4), (1, 3, 5, 9), (3, 3, 8, 33), (1, 3, 2, 40), (2, 3, 63, 31)])
+def test_denoise_edge_sizes_vs_oracle(manifest, shape):
+    """Smallest legal inputs (reflect pad needs pad < dim, utils/util_net.py:24), single rows/columns of tiles, ragged batches."""
+    net, sd, cfg, _ = get_net(manifest, "syn")
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+    x = synth_images(*shape)
+    m = 4
+    pad_h, pad_w = -shape[2] % m, -shape[3] % m
+    if pad_h >= shape[2] or pad_w >= shape[3]:
+        with pytest.raises(RuntimeError, match="pad < dim"):       # the reference's F.pad raises here too
+            net(x.cuda())
+        return
+    with torch.no_grad():
+        mu_ref, sig_ref = cpu_ref.virnet_denoise(sd, x, **kw)
+        mu, sigma = net(x.cuda())
+    assert float((mu.cpu() - mu_ref).abs().max()) <= TIGHT and float((sigma.cpu() - sig_ref).abs().max()) <= TIGHT
+
+
+def test_real_config_cbsd_size_and_sisr_odd_lr(manifest):
+    """Four-level denoise-real config on a 481x321 image (pads to 488x328), and SISR x3 on an odd LR size."""
+    net, sd, cfg, _ = get_net(manifest, "real")
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+    x = synth_images(1, 3, 161, 107)
+    with torch.no_grad():
+        mu_ref, sig_ref = cpu_ref.virnet_denoise(sd, x, **kw)
+        mu, sigma = net(x.cuda())
+    assert float((mu.cpu() - mu_ref).abs().max()) <= 3 * TIGHT and float((sigma.cpu() - sig_ref).abs().max()) <= TIGHT
+    snet, ssd, scfg, _ = get_net(manifest, "sisr")
+    skw = {k: v for k, v in scfg.items() if k not in ("im_chn", "sigma_chn", "kernel_chn")}
+    xl = synth_images(2, 3, 23, 17)
+    with torch.no_grad():
+        mu_r, k_r, s_r = cpu_ref.virnet_sisr(ssd, xl, 3, **skw)
+        mu_s, k_s, s_s = snet(xl.cuda(), 3)
+    assert mu_s.shape == (2, 3, 69, 51) and float((mu_s.cpu() - mu_r).abs().max()) <= TIGHT
+    assert float((k_s.cpu() - k_r).abs().max()) <= 1e-5 and float((s_s.cpu() - s_r).abs().max()) <= 1e-5
