@@ -110,6 +110,19 @@ int virnet_conv_mfma(const virnet_conv_desc* d, void* stream);
 int virnet_conv_mfma_variant(const virnet_conv_desc* d, int out[4]);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same stride-1 3x3 convolution in Winograd F(2x2,3x3) form (16 instead of 36 multiplies per 2x2 output tile and channel
+ * pair; fp32 on v_mfma_f32_32x32x2_f32).  Call sites: AttResBlock.conv1/conv2 (AttResUNet.py:55,58 + residual :59), DnCNN
+ * mid_layer (DnCNN.py:25-28,39-40) and their input-gradient GEMMs in the training step.  Takes the SAME descriptor as
+ * virnet_conv_mfma with ks = 3, stride = 1, epi = VIRNET_EPI_NHWC, cout a multiple of 32 (n_pad = cout; nrep is ignored) and
+ * `wpack` from virnet_pack_wino_weight: U = G g G^T per channel pair, [cout/32][cin_pad/4][16 positions][2][32][2] floats.
+ * `dgrad` = 1 packs the input-gradient GEMM of the layer (W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; pass the forward OIHW tensor
+ * and the FORWARD cout/cin; n_pad then covers cin and cin_pad covers cout, as for kind 2 of virnet_pack_weight).
+ * ---------------------------------------------------------------------------------------------- */
+size_t virnet_wino_weight_floats(int cin_pad, int n_pad);
+int virnet_pack_wino_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
+int virnet_conv_wino(const virnet_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):
  * AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173), DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43),
  * KernelNet.tail conv (KNet.py:49).  Weights: virnet_pack_thin_weight of the OIHW tensor.

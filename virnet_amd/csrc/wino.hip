@@ -1,0 +1,427 @@
+// wino.hip -- the stride-1 3x3 convolution in Winograd F(2x2,3x3) form on the CDNA4 matrix cores (gfx950), fp32.
+//
+// Same call sites as conv_mfma.hip's KS=3,S=1 instantiations (AttResBlock.conv1/conv2, networks/AttResUNet.py:43,46,55,58;
+// DnCNN mid convs, networks/DnCNN.py:25-28) and their input-gradient GEMMs: Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A with
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. 16 multiplies per 2x2 output tile and channel pair instead of 36.  The fp32 matrix pipe is the bound of this path
+// (DESIGN.md 5), so the 2.25x cut in MFMA work is the lever; in fp32 the transform's rounding error is at the level of the direct
+// form's own re-association error (measured against an fp64 run of the whole network: 1.0e-5 vs 0.9e-5 max-abs).
+//
+// The 16 transform positions are 16 independent GEMMs  M_p[cout][tile] = sum_ci U_p[cout][ci] * V_p[ci][tile].
+// Workgroup = 8 waves (two per SIMD), one of two roles, both CB*TG*16 = 64 accumulator blocks of 32x32 per chunk step:
+//   role A <CB=2,TG=2>: 64 output channels x  64 tiles (8 x 32 output pixels)
+//   role B <CB=1,TG=4>: 32 output channels x 128 tiles (16 x 32 output pixels)     (the 32-channel remainder of 96 / 288)
+// A wave owns 32 channels x 32 tiles x 8 of the 16 positions (columns j in {0,1} or {2,3} of the 4x4 position grid):
+// 128 accumulator registers.  The two waves of a pair reduce A^T M A over their column halves, exchange half of the result
+// through LDS once per tile, and each finalises one output row of the 2x2 tiles.
+//
+// K loop: chunks of 4 input channels.  Per chunk, double buffered in LDS:
+//   raw  : the (2*TR+2) x 34 pixel halo tile, 16 B per pixel, activated on the way in (pre-activation of AttResUNet.py:54-55,
+//          zero outside the image AFTER the activation), even/odd columns split so the transform reads contiguous runs
+//   V    : B^T d B, [pos][k-half][tile][2]  (one 8-B MFMA fragment pair per lane, conflict free)
+//   U    : G g G^T from the packed global image, [pos][k-half][cout][2]
+// Iteration c: MFMAs of chunk c read V/U[c&1]; the transform of chunk c+1 runs raw[(c+1)&1] -> V[(c+1)&1]; chunk c+2's pixels
+// and chunk c+1's weights are fetched global -> registers before the MFMAs and landed after them; ONE barrier per chunk.
+// Fragments are read half a chunk ahead of the MFMAs that use them (positions 4..7 of chunk c-1 run after barrier c-1).
+#include "common.h"
+#include "../../include/virnet_hip.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WArgs {
+  const float* x;
+  const float* up;       // packed U: [slab][chunk][pos 16][half 2][32 cout][2]
+  const float* bias;
+  const float* res;
+  const float* mul;
+  const float* add;
+  const float* in_mul;
+  const float* in_add;
+  const float* mask;
+  float* y_raw;
+  float* y_act;
+  int N, H, W, Cin, Cout;
+  int nux, nuy, nunits, units_per_xcd, n64, n32;
+  int in_act;
+  float in_slope, mask_slope, slope;
+};
+
+__device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
+  const f32x4 t = u * s;
+  return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
+}
+
+template <int CB, int TG>
+struct Cfg {
+  static constexpr int TR = 2 * TG;                 // tile rows
+  static constexpr int OHT = 2 * TR;                // output rows
+  static constexpr int IH = OHT + 2, IW = 34;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int RAWB = IH * 2 * 17 * 16;     // [iy][parity][17][16 B]
+  static constexpr int VHALF = TG * 256 + 128;      // +128 B: the two k-halves of one transform write land in disjoint banks
+  static constexpr int VPOS = 2 * VHALF;
+  static constexpr int VB = 16 * VPOS;
+  static constexpr int UROW = CB * 256;             // [pos*2+half] rows of CB*32 channels x 8 B
+  static constexpr int UB = 32 * UROW;
+  static constexpr int STAGE = RAWB + VB + UB;
+  static constexpr int LDS = (2 * STAGE > 65536) ? 2 * STAGE : 65536;   // the result exchange needs 8 x 8 KB
+};
+
+template <int CB, int TG>
+__device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, const int img, const int oy0, const int ox0,
+                                          const int cout_base) {
+  using K = Cfg<CB, TG>;
+  constexpr int NT = 512;
+  constexpr int PPT = (K::NPIX + NT - 1) / NT;       // pixels per thread per chunk
+  constexpr int UPT = CB;                            // 16-B weight pieces per thread per chunk (CB*8 KB / 512 / 16)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nch = a.Cin >> 2;
+  const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+  auto rawbuf = [&](int b) -> char* { return smem + b * K::STAGE; };
+  auto vbuf = [&](int b) -> char* { return smem + b * K::STAGE + K::RAWB; };
+  auto ubuf = [&](int b) -> char* { return smem + b * K::STAGE + K::RAWB + K::VB; };
+
+  // ---- pixel staging: thread -> pixel(s) of the halo tile.  Loads are always issued from a clamped address; the zero fill of
+  // out-of-image pixels is applied when the registers are written to LDS.
+  int poff[PPT], pdst[PPT];
+  bool pinb[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int p = k * NT + tid;
+    const bool has = p < K::NPIX;
+    const int pc = has ? p : 0;
+    const int iy = pc / K::IW, ix = pc - iy * K::IW;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    pinb[k] = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+    poff[k] = (gyc * a.W + gxc) * a.Cin;
+    pdst[k] = has ? ((iy * 2 + (ix & 1)) * 17 + (ix >> 1)) * 16 : -1;
+  }
+  const bool in_sft = a.in_mul != nullptr;
+  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin : nullptr;
+  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin : nullptr;
+  const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  auto load_raw = [&](int chunk, f32x4 (&r)[PPT]) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) r[k] = *reinterpret_cast<const f32x4*>(ximg + poff[k] + chunk * 4);
+  };
+  auto store_raw = [&](char* dstb, int chunk, const f32x4 (&r)[PPT]) {
+    f32x4 m4 = f32x4{1.f, 1.f, 1.f, 1.f}, a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in_sft) {
+      m4 = *reinterpret_cast<const f32x4*>(imul + chunk * 4);
+      a4 = *reinterpret_cast<const f32x4*>(iadd + chunk * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const f32x4 v = lrelu4(r[k] * m4 + a4, in_slope_eff);
+      if (pdst[k] >= 0) *reinterpret_cast<f32x4*>(dstb + pdst[k]) = pinb[k] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  // ---- weight staging: piece q of the chunk image [pos*2+half][CB*32 ch][8 B] <- packed [slab][chunk][pos*2+half][32][2]
+  int uoff[UPT];
+#pragma unroll
+  for (int k = 0; k < UPT; ++k) {
+    const int q = k * NT + tid;
+    const int row = q / (CB * 16), pc = q - row * (CB * 16);
+    const int ch = pc * 2;                                     // channel pair within the CB*32 block
+    const int slab = (cout_base >> 5) + (ch >> 5);
+    uoff[k] = slab * nch * 2048 + row * 64 + (ch & 31) * 2;
+  }
+  auto load_u = [&](int chunk, f32x4 (&r)[UPT]) {
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) r[k] = *reinterpret_cast<const f32x4*>(a.up + uoff[k] + chunk * 2048);
+  };
+  auto store_u = [&](char* dstb, const f32x4 (&r)[UPT]) {
+#pragma unroll
+    for (int k = 0; k < UPT; ++k) *reinterpret_cast<f32x4*>(dstb + (k * NT + tid) * 16) = r[k];
+  };
+  // ---- input transform: item = (tile, row i of B^T d B, k-half); i is wave uniform, lanes = (k-half, tile column, tile-row parity)
+  const int ti = wave & 3;
+  const int ra = (ti == 0) ? 0 : (ti == 2) ? 2 : 1;
+  const int rb = (ti == 3) ? 3 : (ti == 2) ? 1 : 2;
+  const float sgn = (ti == 1) ? 1.f : -1.f;
+  const int h2 = lane & 1, tcol = (lane >> 1) & 15;
+  auto transform = [&](const char* rawb, char* vb) {
+#pragma unroll
+    for (int pass = 0; pass < TG / 2; ++pass) {
+      const int trow = ((wave >> 2) + 2 * pass) * 2 + lhi;
+      const char* const pa = rawb + (2 * trow + ra) * (2 * 17 * 16) + tcol * 16 + h2 * 8;
+      const char* const pb = rawb + (2 * trow + rb) * (2 * 17 * 16) + tcol * 16 + h2 * 8;
+      f32x2 t[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int o = (b & 1) * (17 * 16) + (b >> 1) * 16;
+        t[b] = *reinterpret_cast<const f32x2*>(pa + o) + sgn * *reinterpret_cast<const f32x2*>(pb + o);
+      }
+      char* const dst = vb + (ti * 4) * K::VPOS + h2 * K::VHALF + (trow * 16 + tcol) * 8;
+      *reinterpret_cast<f32x2*>(dst) = t[0] - t[2];
+      *reinterpret_cast<f32x2*>(dst + K::VPOS) = t[1] + t[2];
+      *reinterpret_cast<f32x2*>(dst + 2 * K::VPOS) = t[2] - t[1];
+      *reinterpret_cast<f32x2*>(dst + 3 * K::VPOS) = t[1] - t[3];
+    }
+  };
+  // ---- MFMA role of this wave
+  const int cbw = (CB == 2) ? (wave & 1) : 0;
+  const int tg = (CB == 2) ? ((wave >> 1) & 1) : (wave & 3);
+  const int ph = wave >> 2;                                    // position columns {0,1} or {2,3}
+  const int a_off = (cbw * 32 + l31) * 8 + lhi * K::UROW;      // + pos * 2 * UROW
+  const int b_off = (tg * 32 + l31) * 8 + lhi * K::VHALF;      // + pos * VPOS
+  auto read_frags = [&](const char* ub, const char* vb, int grp, f32x2 (&fa)[4], f32x2 (&fb)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lp = grp * 4 + k;
+      const int pos = (lp >> 1) * 4 + 2 * ph + (lp & 1);
+      fa[k] = *reinterpret_cast<const f32x2*>(ub + a_off + pos * 2 * K::UROW);
+      fb[k] = *reinterpret_cast<const f32x2*>(vb + b_off + pos * K::VPOS);
+    }
+  };
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+  auto mfma_group = [&](int grp, const f32x2 (&fa)[4], const f32x2 (&fb)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[grp * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k].x, fb[k].x, acc[grp * 4 + k], 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[grp * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k].y, fb[k].y, acc[grp * 4 + k], 0, 0, 0);
+  };
+
+  // ---- prologue: chunks 0 and 1 of the pixels, chunk 0 of the weights; transform chunk 0
+  {
+    f32x4 r0[PPT], r1[PPT], u0[UPT];
+    load_raw(0, r0);
+    load_raw(1, r1);
+    load_u(0, u0);
+    store_raw(rawbuf(0), 0, r0);
+    store_raw(rawbuf(1), 1, r1);
+    store_u(ubuf(0), u0);
+  }
+  __syncthreads();
+  transform(rawbuf(0), vbuf(0));
+  __syncthreads();
+
+  f32x2 fa1[4], fb1[4];                                        // fragments of positions 4..7, consumed one iteration later
+  auto iteration = [&](int c, auto first) {
+    const int b = c & 1;
+    f32x2 fa0[4], fb0[4];
+    read_frags(ubuf(b), vbuf(b), 0, fa0, fb0);
+    f32x4 rr[PPT], ur[UPT];
+    const bool more1 = c + 1 < nch, more2 = c + 2 < nch;
+    load_raw(more2 ? c + 2 : c, rr);
+    load_u(more1 ? c + 1 : c, ur);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!decltype(first)::value) mfma_group(1, fa1, fb1);
+    if (more1) transform(rawbuf(b ^ 1), vbuf(b ^ 1));
+    read_frags(ubuf(b), vbuf(b), 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) store_raw(rawbuf(b), c + 2, rr);
+    if (more1) store_u(ubuf(b ^ 1), ur);
+    __syncthreads();
+  };
+  iteration(0, std::true_type{});
+  for (int c = 1; c < nch; ++c) iteration(c, std::false_type{});
+  mfma_group(1, fa1, fb1);
+
+  // ---- output transform.  acc[lp], lp = i*2 + jj, holds M[i][2*ph+jj].  T[a][jj] = (A^T M)[a][j]; the pair's halves of
+  // Y[a][b] = sum_j T[a][j] A[j][b] are  ph 0: {T0+T1, T1}   ph 1: {T2, -T2-T3}.  This wave finalises output row a = ph.
+  f32x16 keep[2], send[2];
+  {
+    f32x16 t0[2], t1[2];                                       // T[0][jj], T[1][jj]
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      t0[jj] = acc[0 + jj] + acc[2 + jj] + acc[4 + jj];
+      t1[jj] = acc[2 + jj] - acc[4 + jj] - acc[6 + jj];
+    }
+    if (ph == 0) {
+      keep[0] = t0[0] + t0[1]; keep[1] = t0[1];                // row a=0
+      send[0] = t1[0] + t1[1]; send[1] = t1[1];                // row a=1 -> partner
+    } else {
+      keep[0] = t1[0]; keep[1] = -t1[0] - t1[1];               // row a=1
+      send[0] = t0[0]; send[1] = -t0[0] - t0[1];               // row a=0 -> partner
+    }
+  }
+  {
+    char* const mine = smem + wave * 8192 + lane * 16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(mine + (b * 4 + g) * 1024) =
+            f32x4{send[b][4 * g], send[b][4 * g + 1], send[b][4 * g + 2], send[b][4 * g + 3]};
+  }
+  __syncthreads();
+  const char* const theirs = smem + (wave ^ 4) * 8192 + lane * 16;
+
+  // ---- epilogue: lane = tile (row tg*2 + l31/16, column l31%16), output row 2*trow + ph, pixels 2*tcol + b; accumulator quad g =
+  // 4 consecutive channels 8g + 4*lhi + (0..3) -> 16-B accesses.
+  const int C = a.Cout;
+  const size_t img_off = (size_t)img * a.H * a.W * C;
+  const float* const rimg = a.res ? a.res + img_off : nullptr;
+  const float* const mimg = a.mask ? a.mask + img_off : nullptr;
+  float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+  float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
+  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
+  const int oy = oy0 + 2 * (tg * 2 + (l31 >> 4)) + ph;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned eo[2];
+  bool ok[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int ox = ox0 + 2 * (l31 & 15) + b;
+    ok[b] = oy < a.H && ox < a.W;
+    eo[b] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C;
+  }
+  f32x4 bias[4], rv[4][2], mv[4][2], yv[4][2];
+  int cog[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    cog[g] = cout_base + cbw * 32 + 8 * g + 4 * lhi;
+    bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cog[g]) : zero4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      rv[g][b] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eo[b] + cog[g]) : zero4;
+      if (mimg) mv[g][b] = *reinterpret_cast<const f32x4*>(mimg + eo[b] + cog[g]);
+      yv[g][b] = *reinterpret_cast<const f32x4*>(theirs + (b * 4 + g) * 1024);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
+    if (mulp) {
+      mul = *reinterpret_cast<const f32x4*>(mulp + cog[g]);
+      add = *reinterpret_cast<const f32x4*>(addp + cog[g]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x4 v = yv[g][b] + f32x4{keep[b][4 * g], keep[b][4 * g + 1], keep[b][4 * g + 2], keep[b][4 * g + 3]} + bias[g];
+      if (mimg) {
+        const f32x4 m = mv[g][b];
+        v = f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
+                  m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+      }
+      v += rv[g][b];
+      if (ok[b]) {
+        if (yraw) *reinterpret_cast<f32x4*>(yraw + eo[b] + cog[g]) = v;
+        if (yact) *reinterpret_cast<f32x4*>(yact + eo[b] + cog[g]) = lrelu4(v * mul + add, a.slope);
+      }
+    }
+  }
+}
+
+constexpr int kWinoLds = (Cfg<2, 2>::LDS > Cfg<1, 4>::LDS) ? Cfg<2, 2>::LDS : Cfg<1, 4>::LDS;
+
+__global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // workgroup -> (unit of 16 x 32 output pixels, slot): slots 0..2*n64-1 are role A (64-channel block slot/2, upper/lower 8 rows),
+  // slot 2*n64 is role B (the 32-channel remainder over all 16 rows).  Block b runs on XCD b%8: units are contiguous per XCD
+  // and the slots of a unit adjacent in time, so the halo tile is fetched from HBM once.
+  const int wpu = 2 * a.n64 + a.n32;
+  const int xcd = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int slot = __builtin_amdgcn_readfirstlane(q % wpu);
+  const int unit = __builtin_amdgcn_readfirstlane(xcd * a.units_per_xcd + q / wpu);
+  if (q / wpu >= a.units_per_xcd || unit >= a.nunits) return;
+  const int ux = __builtin_amdgcn_readfirstlane(unit % a.nux);
+  const int uy = __builtin_amdgcn_readfirstlane((unit / a.nux) % a.nuy);
+  const int img = __builtin_amdgcn_readfirstlane(unit / (a.nux * a.nuy));
+  if (slot < 2 * a.n64) {
+    const int oy0 = uy * 16 + (slot & 1) * 8;
+    if (oy0 >= a.H) return;
+    wino_body<2, 2>(a, smem, img, oy0, ux * 32, (slot >> 1) * 64);
+  } else {
+    wino_body<1, 4>(a, smem, img, uy * 16, ux * 32, a.n64 * 64);
+  }
+}
+
+// U = G g G^T of every (output channel, input channel) pair, in the chunk-stage layout the kernel copies linearly.
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int dgrad, int cout, int cin, int cin_pad,
+                                 int n_pad) {
+  const int nch = cin_pad >> 2;
+  const long total = (long)(n_pad >> 5) * nch * 2048;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int s = idx & 1, col = (idx >> 1) & 31, half = (idx >> 6) & 1, pos = (idx >> 7) & 15;
+  const long sc = idx >> 11;
+  const int chunk = (int)(sc % nch), slab = (int)(sc / nch);
+  const int co = slab * 32 + col, ci = chunk * 4 + half * 2 + s;
+  // GEMM extents: forward (cout, cin); dgrad (cin_fwd, cout_fwd) with flipped taps
+  const int rows = dgrad ? cin : cout, ks = dgrad ? cout : cin;
+  float u = 0.f;
+  if (co < rows && ci < ks) {
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx)
+        g[ky][kx] = dgrad ? (double)w[(((size_t)ci * cin + co) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                          : (double)w[(((size_t)co * cin + ci) * 3 + ky) * 3 + kx];
+    const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    const int i = pos >> 2, j = pos & 3;
+    double acc = 0;
+    for (int p = 0; p < 3; ++p)
+      for (int r = 0; r < 3; ++r) acc += G[i][p] * g[p][r] * G[j][r];
+    u = (float)acc;
+  }
+  out[idx] = u;
+}
+
+}  // namespace
+
+extern "C" size_t virnet_wino_weight_floats(int cin_pad, int n_pad) { return (size_t)n_pad * cin_pad * 16; }
+
+extern "C" int virnet_pack_wino_weight(const float* w, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed,
+                                       void* stream) {
+  VIRNET_REQUIRE(w && packed, "virnet_pack_wino_weight: NULL pointer");
+  VIRNET_REQUIRE(cout > 0 && cin > 0, "virnet_pack_wino_weight: bad extents cout=%d cin=%d", cout, cin);
+  const int rows = dgrad ? cin : cout, ks = dgrad ? cout : cin;
+  VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= ks, "virnet_pack_wino_weight: cin_pad=%d does not cover %d contraction channels", cin_pad, ks);
+  VIRNET_REQUIRE(n_pad % 32 == 0 && n_pad >= rows, "virnet_pack_wino_weight: n_pad=%d does not cover %d output channels", n_pad, rows);
+  const long total = (long)n_pad * cin_pad * 16;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed,
+                     dgrad, cout, cin, cin_pad, n_pad);
+  return virnet::check_launch("pack_wino launch");
+}
+
+extern "C" int virnet_conv_wino(const virnet_conv_desc* d, void* stream) {
+  VIRNET_REQUIRE(d != nullptr, "virnet_conv_wino: desc is NULL");
+  VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_wino: x / wpack is NULL");
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_wino: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
+                 d->ks, d->stride, d->epi);
+  VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_wino: empty input n=%d h=%d w=%d", d->n, d->h, d->w);
+  VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_wino: cin_pad=%d is not a multiple of 16", d->cin_pad);
+  VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_wino: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
+  VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_wino: no output pointer");
+  VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_wino: in_mul and in_add must be given together");
+  VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_wino: in_mul/in_add without in_act");
+  VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_wino: in_slope=%g outside [0,1]", d->in_slope);
+  VIRNET_REQUIRE(!d->y_act || (d->slope >= 0.f && d->slope <= 1.f), "virnet_conv_wino: slope=%g outside [0,1]", d->slope);
+  WArgs k{};
+  k.x = d->x; k.up = d->wpack; k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
+  k.in_mul = d->in_mul; k.in_add = d->in_add; k.mask = d->mask; k.y_raw = d->y_raw; k.y_act = d->y_act;
+  k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.Cout = d->cout;
+  k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
+  k.n64 = d->cout / 64; k.n32 = (d->cout % 64) / 32;
+  k.nux = (d->w + 31) / 32; k.nuy = (d->h + 15) / 16;
+  k.nunits = d->n * k.nux * k.nuy;
+  k.units_per_xcd = (k.nunits + 7) / 8;
+  static unsigned long long attr_done = 0;
+  if (virnet::first_use_on_device(attr_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wino): %s", hipGetErrorString(e));
+  }
+  const unsigned grid = (unsigned)(8 * k.units_per_xcd * (2 * k.n64 + k.n32));
+  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), kWinoLds, static_cast<hipStream_t>(stream), k);
+  return virnet::check_launch("conv_wino launch");
+}

@@ -28,6 +28,7 @@ class PackedWeight:
     n_pad: int
     nrep: int
     transposed: bool
+    wino: Optional[Tensor] = None   # Winograd-domain image (virnet_pack_wino_weight) of a stride-1 3x3 layer, when eligible
 
 
 class LaunchTimer:
@@ -57,18 +58,51 @@ def set_launch_timer(t: Optional[LaunchTimer]) -> None:
     _TIMER = t
 
 
-def _launch_conv(d: "nat.ConvDesc", flops: float, what: str) -> None:
+def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, wino: bool = False) -> None:
     lib = nat.load()
+    fn = lib.virnet_conv_wino if wino else lib.virnet_conv_mfma
     if _TIMER is None:
-        nat.check(lib.virnet_conv_mfma(C.byref(d), nat.stream_handle()), what)
+        nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
-    var = (C.c_int * 4)()
-    nat.check(lib.virnet_conv_mfma_variant(C.byref(d), C.byref(var)), what)
+    if wino:
+        key = ("wino", d.cout)
+    else:
+        var = (C.c_int * 4)()
+        nat.check(lib.virnet_conv_mfma_variant(C.byref(d), C.byref(var)), what)
+        key = tuple(var)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    nat.check(lib.virnet_conv_mfma(C.byref(d), nat.stream_handle()), what)
+    nat.check(fn(C.byref(d), nat.stream_handle()), what)
     e1.record()
-    _TIMER.records.append((tuple(var), flops, e0, e1))
+    _TIMER.records.append((key, flops, e0, e1))
+
+
+# The Winograd form serves every stride-1 3x3 layer whose channel counts fill MFMA blocks; VIRNET_WINOGRAD=0 keeps the direct form
+# (tuning / A-B runs).
+WINO_MIN_CHANNELS = 32
+
+
+def _wino_enabled() -> bool:
+    import os
+    return os.environ.get("VIRNET_WINOGRAD", "1") != "0"
+
+
+def pack_wino_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
+    """G g G^T image of an OIHW 3x3 weight for virnet_conv_wino (``dgrad``: of the layer's input-gradient GEMM)."""
+    lib = nat.load()
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("the Winograd form is for 3x3 kernels")
+    rows, ks = (cin, cout) if dgrad else (cout, cin)
+    if rows % 32:
+        raise ValueError(f"the Winograd kernel stores multiples of 32 channels, got {rows}")
+    cin_pad = (ks + 15) // 16 * 16
+    out = torch.empty(lib.virnet_wino_weight_floats(cin_pad, rows), dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_wino_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, rows, nat.ptr(out), nat.stream_handle()),
+              "pack_wino_weight")
+    return out
 
 
 def _dev_check(t: Tensor, name: str) -> None:
@@ -111,7 +145,10 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         out = torch.empty(n, dtype=torch.float32, device=weight.device)
         nat.check(lib.virnet_pack_weight(nat.ptr(weight), kind, cout, cin, ks, plan.cin_pad, plan.n_pad, plan.nrep, nat.ptr(out),
                                          nat.stream_handle()), "pack_weight(dgrad)")
-        return PackedWeight(out, None, gemm_ks, cin, (4 * cout if transposed else cout), plan.cin_pad, plan.n_pad, plan.nrep, False)
+        pw = PackedWeight(out, None, gemm_ks, cin, (4 * cout if transposed else cout), plan.cin_pad, plan.n_pad, plan.nrep, False)
+        if not transposed and _wino_enabled() and cin % 32 == 0 and cout >= WINO_MIN_CHANNELS:
+            pw.wino = pack_wino_weight(weight, dgrad=True)
+        return pw
     if transposed:
         cin, cout, kh, kw = weight.shape
         if (kh, kw) != (2, 2):
@@ -132,7 +169,10 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
     if bias is not None:
         b = bias.detach()
         _dev_check(b, "bias")
-    return PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
+    pw = PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
+    if kind == 0 and ks == 3 and stride == 1 and _wino_enabled() and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
+        pw.wino = pack_wino_weight(weight)
+    return pw
 
 
 def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
@@ -166,14 +206,15 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         raise ValueError(f"in_mul/in_add must be [{n}, {c}]")
     if res is not None and tuple(res.shape) != (n, oh, ow, cstore):
         raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, cstore)}")
-    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
+    wino = pw.wino is not None and stride == 1 and epi == nat.EPI_NHWC and cstore == pw.cout and _wino_enabled()
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.wino if wino else pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
                      stride=stride, epi=epi, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=int(in_slope is not None),
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
-    _launch_conv(d, flops, "conv_mfma")
+    _launch_conv(d, flops, "conv_wino" if wino else "conv_mfma", wino)
     return raw, act
 
 
