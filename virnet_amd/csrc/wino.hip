@@ -8,9 +8,11 @@
 // form's own re-association error (measured against an fp64 run of the whole network: 1.0e-5 vs 0.9e-5 max-abs).
 //
 // The 16 transform positions are 16 independent GEMMs  M_p[cout][tile] = sum_ci U_p[cout][ci] * V_p[ci][tile].
-// Workgroup = 8 waves (two per SIMD), one of two roles, both CB*TG*16 = 64 accumulator blocks of 32x32 per chunk step:
-//   role A <CB=2,TG=2>: 64 output channels x  64 tiles (8 x 32 output pixels)
-//   role B <CB=1,TG=4>: 32 output channels x 128 tiles (16 x 32 output pixels)     (the 32-channel remainder of 96 / 288)
+// Workgroup = CB*TG*2 waves, one of two roles with the same number of accumulator blocks; two sizes are instantiated:
+//   8 waves, one workgroup per CU : role A <CB=2,TG=2> 64 channels x  64 tiles (8 x 32 output pixels)
+//                                   role B <CB=1,TG=4> 32 channels x 128 tiles (16 x 32 pixels; the 32-channel remainder of 96 / 288)
+//   4 waves, two workgroups per CU: role A <2,1> 64 channels x 32 tiles, role B <1,2> 32 channels x 64 tiles (small grids)
+// The weight image U is re-read per workgroup and per chunk, so the tile count per workgroup sets the weight traffic.
 // A wave owns 32 channels x 32 tiles x 8 of the 16 positions (columns j in {0,1} or {2,3} of the 4x4 position grid):
 // 128 accumulator registers.  The two waves of a pair reduce A^T M A over their column halves, exchange half of the result
 // through LDS once per tile, and each finalises one output row of the 2x2 tiles.
@@ -19,12 +21,15 @@
 //   raw  : the (2*TR+2) x 34 pixel halo tile, 16 B per pixel, activated on the way in (pre-activation of AttResUNet.py:54-55,
 //          zero outside the image AFTER the activation), even/odd columns split so the transform reads contiguous runs
 //   V    : B^T d B, [pos][k-half][tile][2]  (one 8-B MFMA fragment pair per lane, conflict free)
-//   U    : G g G^T from the packed global image, [pos][k-half][cout][2]
+//   U    : G g G^T from the packed global image, [pos][k-half][cout][2], copied global -> LDS by the DMA path
+//          (global_load_lds_dwordx4: no VGPR round trip, which would cost matrix-pipe time -- profiles/r01_probes.md)
 // Iteration c: MFMAs of chunk c read V/U[c&1]; the transform of chunk c+1 runs raw[(c+1)&1] -> V[(c+1)&1]; chunk c+2's pixels
-// and chunk c+1's weights are fetched global -> registers before the MFMAs and landed after them; ONE barrier per chunk.
+// are fetched global -> registers before the MFMAs and landed after them, chunk c+1's weights stream into U[(c+1)&1]; ONE
+// barrier per chunk.
 // Fragments are read half a chunk ahead of the MFMAs that use them (positions 4..7 of chunk c-1 run after barrier c-1).
 #include "common.h"
 #include "../../include/virnet_hip.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -58,6 +63,7 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
 
 template <int CB, int TG>
 struct Cfg {
+  static constexpr int NW = CB * TG * 2;            // waves
   static constexpr int TR = 2 * TG;                 // tile rows
   static constexpr int OHT = 2 * TR;                // output rows
   static constexpr int IH = OHT + 2, IW = 34;
@@ -69,16 +75,20 @@ struct Cfg {
   static constexpr int UROW = CB * 256;             // [pos*2+half] rows of CB*32 channels x 8 B
   static constexpr int UB = 32 * UROW;
   static constexpr int STAGE = RAWB + VB + UB;
-  static constexpr int LDS = (2 * STAGE > 65536) ? 2 * STAGE : 65536;   // the result exchange needs 8 x 8 KB
+  static constexpr int XCH = NW * 8192;             // result exchange: 8 KB per wave
+  static constexpr int LDS = (2 * STAGE > XCH) ? 2 * STAGE : XCH;
 };
 
-template <int CB, int TG>
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int CB, int TG, bool SFT>
 __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, const int img, const int oy0, const int ox0,
                                           const int cout_base) {
   using K = Cfg<CB, TG>;
-  constexpr int NT = 512;
+  constexpr int NW = K::NW, NT = NW * 64;
   constexpr int PPT = (K::NPIX + NT - 1) / NT;       // pixels per thread per chunk
-  constexpr int UPT = CB;                            // 16-B weight pieces per thread per chunk (CB*8 KB / 512 / 16)
+  constexpr int UPW = 4 / TG;                        // 1-KB DMA pieces per wave per chunk (CB*8 KB / NW)
+  constexpr int XP = 2 / CB;                         // transform items per thread per chunk
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,14 +97,11 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
   const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
-  auto rawbuf = [&](int b) -> char* { return smem + b * K::STAGE; };
-  auto vbuf = [&](int b) -> char* { return smem + b * K::STAGE + K::RAWB; };
-  auto ubuf = [&](int b) -> char* { return smem + b * K::STAGE + K::RAWB + K::VB; };
-
-  // ---- pixel staging: thread -> pixel(s) of the halo tile.  Loads are always issued from a clamped address; the zero fill of
-  // out-of-image pixels is applied when the registers are written to LDS.
+  // ---- pixel staging: thread -> pixel(s) of the halo tile.  Loads are always issued from a clamped address; out-of-image
+  // pixels become zero on their way into LDS (after the activation: the conv pads the ACTIVATED tensor).
   int poff[PPT], pdst[PPT];
   bool pinb[PPT];
+  float pmsk[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int p = k * NT + tid;
@@ -103,84 +110,84 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
     const int iy = pc / K::IW, ix = pc - iy * K::IW;
     const int gy = iy0 + iy, gx = ix0 + ix;
     pinb[k] = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    pmsk[k] = pinb[k] ? 1.f : 0.f;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
     poff[k] = (gyc * a.W + gxc) * a.Cin;
     pdst[k] = has ? ((iy * 2 + (ix & 1)) * 17 + (ix >> 1)) * 16 : -1;
   }
-  const bool in_sft = a.in_mul != nullptr;
-  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin : nullptr;
-  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin : nullptr;
+  const float* const imul = SFT ? a.in_mul + (size_t)img * a.Cin : nullptr;
+  const float* const iadd = SFT ? a.in_add + (size_t)img * a.Cin : nullptr;
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
-  auto load_raw = [&](int chunk, f32x4 (&r)[PPT]) {
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) r[k] = *reinterpret_cast<const f32x4*>(ximg + poff[k] + chunk * 4);
-  };
-  auto store_raw = [&](char* dstb, int chunk, const f32x4 (&r)[PPT]) {
-    f32x4 m4 = f32x4{1.f, 1.f, 1.f, 1.f}, a4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (in_sft) {
-      m4 = *reinterpret_cast<const f32x4*>(imul + chunk * 4);
-      a4 = *reinterpret_cast<const f32x4*>(iadd + chunk * 4);
+  auto load_raw1 = [&](int chunk, int k) -> f32x4 { return *reinterpret_cast<const f32x4*>(ximg + poff[k] + chunk * 4); };
+  // lrelu(x*mul+add) then zero outside the image.  Without SFT the image mask is folded into the multiply: lrelu(0) == 0.
+  auto store_raw1 = [&](char* dstb, int chunk, int k, f32x4 r) {
+    f32x4 v;
+    if (SFT) {
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(imul + chunk * 4);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(iadd + chunk * 4);
+      v = lrelu4(r * m4 + a4, in_slope_eff);
+      v = pinb[k] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      v = lrelu4(r * pmsk[k], in_slope_eff);
     }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      const f32x4 v = lrelu4(r[k] * m4 + a4, in_slope_eff);
-      if (pdst[k] >= 0) *reinterpret_cast<f32x4*>(dstb + pdst[k]) = pinb[k] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    if (pdst[k] >= 0) *reinterpret_cast<f32x4*>(dstb + pdst[k]) = v;
   };
-  // ---- weight staging: piece q of the chunk image [pos*2+half][CB*32 ch][8 B] <- packed [slab][chunk][pos*2+half][32][2]
-  int uoff[UPT];
+  // ---- weight staging: 1-KB piece q of the chunk image [pos*2+half][CB*32 ch][8 B] <- packed [slab][chunk][pos*2+half][32][2].
+  // The DMA writes LDS at (wave-uniform base) + lane*16, so lane l of piece q supplies the global address of byte q*1024 + l*16.
+  int uoff[UPW];
 #pragma unroll
-  for (int k = 0; k < UPT; ++k) {
-    const int q = k * NT + tid;
-    const int row = q / (CB * 16), pc = q - row * (CB * 16);
+  for (int k = 0; k < UPW; ++k) {
+    const int q16 = (wave * UPW + k) * 64 + lane;                // 16-B piece index within the chunk image
+    const int row = q16 / (CB * 16), pc = q16 - row * (CB * 16);
     const int ch = pc * 2;                                     // channel pair within the CB*32 block
     const int slab = (cout_base >> 5) + (ch >> 5);
     uoff[k] = slab * nch * 2048 + row * 64 + (ch & 31) * 2;
   }
-  auto load_u = [&](int chunk, f32x4 (&r)[UPT]) {
+  auto dma_u = [&](int chunk, char* dstb) {
 #pragma unroll
-    for (int k = 0; k < UPT; ++k) r[k] = *reinterpret_cast<const f32x4*>(a.up + uoff[k] + chunk * 2048);
+    for (int k = 0; k < UPW; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.up + uoff[k] + chunk * 2048),
+                                       (__attribute__((address_space(3))) void*)(dstb + (wave * UPW + k) * 1024), 16, 0, 0);
   };
-  auto store_u = [&](char* dstb, const f32x4 (&r)[UPT]) {
-#pragma unroll
-    for (int k = 0; k < UPT; ++k) *reinterpret_cast<f32x4*>(dstb + (k * NT + tid) * 16) = r[k];
-  };
-  // ---- input transform: item = (tile, row i of B^T d B, k-half); i is wave uniform, lanes = (k-half, tile column, tile-row parity)
-  const int ti = wave & 3;
+  // ---- input transform: item = (tile, row i of B^T d B, k-half); i = wave%4 (uniform), lanes = (k-half, tile column, row parity)
+  const int ti = wave & 3, tq = wave >> 2;
   const int ra = (ti == 0) ? 0 : (ti == 2) ? 2 : 1;
   const int rb = (ti == 3) ? 3 : (ti == 2) ? 1 : 2;
   const float sgn = (ti == 1) ? 1.f : -1.f;
   const int h2 = lane & 1, tcol = (lane >> 1) & 15;
-  auto transform = [&](const char* rawb, char* vb) {
+  const int xr_a = (2 * (2 * tq + lhi) + ra) * (2 * 17 * 16) + tcol * 16 + h2 * 8;      // + pass * (NW/4) * 4 rows
+  const int xr_b = (2 * (2 * tq + lhi) + rb) * (2 * 17 * 16) + tcol * 16 + h2 * 8;
+  const int xw_o = (ti * 4) * K::VPOS + h2 * K::VHALF + ((2 * tq + lhi) * 16 + tcol) * 8;  // + pass * (NW/4) * 2 tile rows
+  constexpr int XR_PASS = (NW / 4) * 4 * (2 * 17 * 16), XW_PASS = (NW / 4) * 2 * 16 * 8;
+  auto xf_read1 = [&](const char* rawb, int pass, f32x2 (&da)[4], f32x2 (&db)[4]) {
 #pragma unroll
-    for (int pass = 0; pass < TG / 2; ++pass) {
-      const int trow = ((wave >> 2) + 2 * pass) * 2 + lhi;
-      const char* const pa = rawb + (2 * trow + ra) * (2 * 17 * 16) + tcol * 16 + h2 * 8;
-      const char* const pb = rawb + (2 * trow + rb) * (2 * 17 * 16) + tcol * 16 + h2 * 8;
-      f32x2 t[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int o = (b & 1) * (17 * 16) + (b >> 1) * 16;
-        t[b] = *reinterpret_cast<const f32x2*>(pa + o) + sgn * *reinterpret_cast<const f32x2*>(pb + o);
-      }
-      char* const dst = vb + (ti * 4) * K::VPOS + h2 * K::VHALF + (trow * 16 + tcol) * 8;
-      *reinterpret_cast<f32x2*>(dst) = t[0] - t[2];
-      *reinterpret_cast<f32x2*>(dst + K::VPOS) = t[1] + t[2];
-      *reinterpret_cast<f32x2*>(dst + 2 * K::VPOS) = t[2] - t[1];
-      *reinterpret_cast<f32x2*>(dst + 3 * K::VPOS) = t[1] - t[3];
+    for (int b = 0; b < 4; ++b) {
+      const int o = (b & 1) * (17 * 16) + (b >> 1) * 16 + pass * XR_PASS;
+      da[b] = *reinterpret_cast<const f32x2*>(rawb + xr_a + o);
+      db[b] = *reinterpret_cast<const f32x2*>(rawb + xr_b + o);
     }
   };
+  auto xf_write1 = [&](char* vb, int pass, const f32x2 (&da)[4], const f32x2 (&db)[4]) {
+    f32x2 t[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) t[b] = da[b] + sgn * db[b];
+    char* const dst = vb + xw_o + pass * XW_PASS;
+    *reinterpret_cast<f32x2*>(dst) = t[0] - t[2];
+    *reinterpret_cast<f32x2*>(dst + K::VPOS) = t[1] + t[2];
+    *reinterpret_cast<f32x2*>(dst + 2 * K::VPOS) = t[2] - t[1];
+    *reinterpret_cast<f32x2*>(dst + 3 * K::VPOS) = t[1] - t[3];
+  };
   // ---- MFMA role of this wave
-  const int cbw = (CB == 2) ? (wave & 1) : 0;
-  const int tg = (CB == 2) ? ((wave >> 1) & 1) : (wave & 3);
-  const int ph = wave >> 2;                                    // position columns {0,1} or {2,3}
-  const int a_off = (cbw * 32 + l31) * 8 + lhi * K::UROW;      // + pos * 2 * UROW
-  const int b_off = (tg * 32 + l31) * 8 + lhi * K::VHALF;      // + pos * VPOS
+  const int cbw = wave % CB;
+  const int tg = (wave / CB) % TG;
+  const int ph = wave / (CB * TG);                             // position columns {0,1} or {2,3}
+  const int a_off = (cbw * 32 + l31) * 8 + lhi * K::UROW + 2 * ph * 2 * K::UROW;   // + (4*i + jj) * 2 * UROW
+  const int b_off = (tg * 32 + l31) * 8 + lhi * K::VHALF + 2 * ph * K::VPOS;       // + (4*i + jj) * VPOS
   auto read_frags = [&](const char* ub, const char* vb, int grp, f32x2 (&fa)[4], f32x2 (&fb)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int lp = grp * 4 + k;
-      const int pos = (lp >> 1) * 4 + 2 * ph + (lp & 1);
+      const int pos = (lp >> 1) * 4 + (lp & 1);
       fa[k] = *reinterpret_cast<const f32x2*>(ub + a_off + pos * 2 * K::UROW);
       fb[k] = *reinterpret_cast<const f32x2*>(vb + b_off + pos * K::VPOS);
     }
@@ -190,52 +197,130 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   for (int p = 0; p < 8; ++p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-  auto mfma_group = [&](int grp, const f32x2 (&fa)[4], const f32x2 (&fb)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[grp * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k].x, fb[k].x, acc[grp * 4 + k], 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[grp * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k].y, fb[k].y, acc[grp * 4 + k], 0, 0, 0);
+  auto mf = [&](int lp, int ks, const f32x2 (&fa)[4], const f32x2 (&fb)[4]) {
+    acc[lp] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks ? fa[lp & 3].y : fa[lp & 3].x, ks ? fb[lp & 3].y : fb[lp & 3].x, acc[lp], 0, 0, 0);
   };
 
+  constexpr int RAW0 = 0, V0 = K::RAWB, U0 = K::RAWB + K::VB;
   // ---- prologue: chunks 0 and 1 of the pixels, chunk 0 of the weights; transform chunk 0
   {
-    f32x4 r0[PPT], r1[PPT], u0[UPT];
-    load_raw(0, r0);
-    load_raw(1, r1);
-    load_u(0, u0);
-    store_raw(rawbuf(0), 0, r0);
-    store_raw(rawbuf(1), 1, r1);
-    store_u(ubuf(0), u0);
+    dma_u(0, smem + U0);
+    f32x4 r0[PPT], r1[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) { r0[k] = load_raw1(0, k); r1[k] = load_raw1(1, k); }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) { store_raw1(smem + RAW0, 0, k, r0[k]); store_raw1(smem + K::STAGE + RAW0, 1, k, r1[k]); }
   }
   __syncthreads();
-  transform(rawbuf(0), vbuf(0));
+#pragma unroll
+  for (int pass = 0; pass < XP; ++pass) {
+    f32x2 da[4], db[4];
+    xf_read1(smem + RAW0, pass, da, db);
+    xf_write1(smem + V0, pass, da, db);
+  }
   __syncthreads();
 
   f32x2 fa1[4], fb1[4];                                        // fragments of positions 4..7, consumed one iteration later
-  auto iteration = [&](int c, auto first) {
-    const int b = c & 1;
-    f32x2 fa0[4], fb0[4];
-    read_frags(ubuf(b), vbuf(b), 0, fa0, fb0);
-    f32x4 rr[PPT], ur[UPT];
+  // One chunk (buffers B compile-time: the loop is unrolled by two so every LDS address is a loop-invariant base + immediate).
+  // A wave issues in order and blocks on the busy matrix pipe, so everything else is threaded BETWEEN its 16 MFMAs: each
+  // piece runs under the MFMA issued before it, and the two waves of a SIMD keep the pipe fed through each other's pieces.
+  auto iteration = [&](int c, auto bsel, auto first) {
+    constexpr int B = decltype(bsel)::value;
+    constexpr bool FIRST = decltype(first)::value;
+    char* const st_cur = smem + B * K::STAGE;
+    char* const st_nxt = smem + (B ^ 1) * K::STAGE;
     const bool more1 = c + 1 < nch, more2 = c + 2 < nch;
-    load_raw(more2 ? c + 2 : c, rr);
-    load_u(more1 ? c + 1 : c, ur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!decltype(first)::value) mfma_group(1, fa1, fb1);
-    if (more1) transform(rawbuf(b ^ 1), vbuf(b ^ 1));
-    read_frags(ubuf(b), vbuf(b), 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) store_raw(rawbuf(b), c + 2, rr);
-    if (more1) store_u(ubuf(b ^ 1), ur);
+    f32x2 fa0[4], fb0[4];
+    f32x4 rr[PPT];
+    f32x2 da[XP][4], db[XP][4];
+    if (!FIRST) mf(4, 0, fa1, fb1);
+    SB();
+    read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
+    SB();
+    if (!FIRST) mf(5, 0, fa1, fb1);
+    SB();
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) rr[k] = load_raw1(more2 ? c + 2 : c, k);
+    if (more1) dma_u(c + 1, st_nxt + U0);
+    SB();
+    if (!FIRST) mf(6, 0, fa1, fb1);
+    SB();
+    xf_read1(st_nxt + RAW0, 0, da[0], db[0]);
+    SB();
+    if (!FIRST) mf(7, 0, fa1, fb1);
+    SB();
+    if (XP == 2) xf_read1(st_nxt + RAW0, XP - 1, da[XP - 1], db[XP - 1]);
+    SB();
+    if (!FIRST) { mf(4, 1, fa1, fb1); mf(5, 1, fa1, fb1); }
+    SB();
+    if (more1) xf_write1(st_nxt + V0, 0, da[0], db[0]);
+    SB();
+    if (!FIRST) { mf(6, 1, fa1, fb1); mf(7, 1, fa1, fb1); }
+    SB();
+    if (XP == 2 && more1) xf_write1(st_nxt + V0, XP - 1, da[XP - 1], db[XP - 1]);
+    SB();
+    mf(0, 0, fa0, fb0); mf(1, 0, fa0, fb0);
+    SB();
+    if (more2) store_raw1(st_cur + RAW0, c + 2, 0, rr[0]);
+    SB();
+    mf(2, 0, fa0, fb0);
+    SB();
+    if (PPT == 2 && more2) store_raw1(st_cur + RAW0, c + 2, PPT - 1, rr[PPT - 1]);
+    SB();
+    mf(3, 0, fa0, fb0);
+    SB();
+    read_frags(st_cur + U0, st_cur + V0, 1, fa1, fb1);
+    SB();
+    mf(0, 1, fa0, fb0); mf(1, 1, fa0, fb0); mf(2, 1, fa0, fb0); mf(3, 1, fa0, fb0);
+    SB();
     __syncthreads();
   };
-  iteration(0, std::true_type{});
-  for (int c = 1; c < nch; ++c) iteration(c, std::false_type{});
-  mfma_group(1, fa1, fb1);
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  iteration(0, I0{}, std::true_type{});
+  for (int c = 1; c + 1 < nch; c += 2) {
+    iteration(c, I1{}, std::false_type{});
+    iteration(c + 1, I0{}, std::false_type{});
+  }
+  iteration(nch - 1, I1{}, std::false_type{});
 
-  // ---- output transform.  acc[lp], lp = i*2 + jj, holds M[i][2*ph+jj].  T[a][jj] = (A^T M)[a][j]; the pair's halves of
+  // ---- epilogue.  Lane = tile (row tg*2 + l31/16, column l31%16); this wave finalises output row 2*trow + ph, pixels
+  // 2*tcol + b; accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3) -> 16-B accesses.  The residual and bias loads
+  // are issued before the last MFMAs and the exchange so their latency is covered.
+  const int C = a.Cout;
+  const size_t img_off = (size_t)img * a.H * a.W * C;
+  const float* const rimg = a.res ? a.res + img_off : nullptr;
+  const float* const mimg = a.mask ? a.mask + img_off : nullptr;
+  float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+  float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
+  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
+  const int oy = oy0 + 2 * (tg * 2 + (l31 >> 4)) + ph;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned eo[2];
+  bool ok[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int ox = ox0 + 2 * (l31 & 15) + b;
+    ok[b] = oy < a.H && ox < a.W;
+    eo[b] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C;
+  }
+  f32x4 bias[4], rv[4][2];
+  int cog[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    cog[g] = cout_base + cbw * 32 + 8 * g + 4 * lhi;
+    bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cog[g]) : zero4;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) rv[g][b] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eo[b] + cog[g]) : zero4;
+  }
+  SB();
+#pragma unroll
+  for (int lp = 4; lp < 8; ++lp) mf(lp, 0, fa1, fb1);
+#pragma unroll
+  for (int lp = 4; lp < 8; ++lp) mf(lp, 1, fa1, fb1);
+
+  // output transform.  acc[lp], lp = i*2 + jj, holds M[i][2*ph+jj].  T[a][jj] = (A^T M)[a][j]; the pair's halves of
   // Y[a][b] = sum_j T[a][j] A[j][b] are  ph 0: {T0+T1, T1}   ph 1: {T2, -T2-T3}.  This wave finalises output row a = ph.
   f32x16 keep[2], send[2];
   {
@@ -263,41 +348,15 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
             f32x4{send[b][4 * g], send[b][4 * g + 1], send[b][4 * g + 2], send[b][4 * g + 3]};
   }
   __syncthreads();
-  const char* const theirs = smem + (wave ^ 4) * 8192 + lane * 16;
-
-  // ---- epilogue: lane = tile (row tg*2 + l31/16, column l31%16), output row 2*trow + ph, pixels 2*tcol + b; accumulator quad g =
-  // 4 consecutive channels 8g + 4*lhi + (0..3) -> 16-B accesses.
-  const int C = a.Cout;
-  const size_t img_off = (size_t)img * a.H * a.W * C;
-  const float* const rimg = a.res ? a.res + img_off : nullptr;
-  const float* const mimg = a.mask ? a.mask + img_off : nullptr;
-  float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
-  float* const yact = a.y_act ? a.y_act + img_off : nullptr;
-  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
-  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
-  const int oy = oy0 + 2 * (tg * 2 + (l31 >> 4)) + ph;
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  unsigned eo[2];
-  bool ok[2];
+  const char* const theirs = smem + (wave ^ (CB * TG)) * 8192 + lane * 16;
+  f32x4 mv[4][2], yv[4][2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int ox = ox0 + 2 * (l31 & 15) + b;
-    ok[b] = oy < a.H && ox < a.W;
-    eo[b] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C;
-  }
-  f32x4 bias[4], rv[4][2], mv[4][2], yv[4][2];
-  int cog[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    cog[g] = cout_base + cbw * 32 + 8 * g + 4 * lhi;
-    bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cog[g]) : zero4;
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      rv[g][b] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eo[b] + cog[g]) : zero4;
       if (mimg) mv[g][b] = *reinterpret_cast<const f32x4*>(mimg + eo[b] + cog[g]);
       yv[g][b] = *reinterpret_cast<const f32x4*>(theirs + (b * 4 + g) * 1024);
     }
-  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
@@ -322,13 +381,21 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   }
 }
 
-constexpr int kWinoLds = (Cfg<2, 2>::LDS > Cfg<1, 4>::LDS) ? Cfg<2, 2>::LDS : Cfg<1, 4>::LDS;
+// NW8 = true: 8-wave workgroups (roles <2,2> / <1,4>, unit = 16 x 32 output pixels); false: 4-wave workgroups (<2,1> / <1,2>,
+// unit = 8 x 32).  Workgroup -> (unit, slot): slots 0..2*n64-1 are role A (64-channel block slot/2, upper/lower half of the unit),
+// slot 2*n64 is role B (the 32-channel remainder over the whole unit).  Block b runs on XCD b%8: units are contiguous per XCD and
+// the slots of a unit adjacent in time, so the halo tile is fetched from HBM once.
+template <bool NW8>
+struct Roles {
+  static constexpr int TGA = NW8 ? 2 : 1, TGB = NW8 ? 4 : 2;
+  static constexpr int UH = 4 * TGB;                // unit height in output rows
+  static constexpr int LDS = (Cfg<2, TGA>::LDS > Cfg<1, TGB>::LDS) ? Cfg<2, TGA>::LDS : Cfg<1, TGB>::LDS;
+};
 
-__global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WArgs a) {
+template <bool NW8, bool SFT>
+__global__ __launch_bounds__(NW8 ? 512 : 256, NW8 ? 1 : 2) void conv_wino_kernel(const WArgs a) {
+  using R = Roles<NW8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // workgroup -> (unit of 16 x 32 output pixels, slot): slots 0..2*n64-1 are role A (64-channel block slot/2, upper/lower 8 rows),
-  // slot 2*n64 is role B (the 32-channel remainder over all 16 rows).  Block b runs on XCD b%8: units are contiguous per XCD
-  // and the slots of a unit adjacent in time, so the halo tile is fetched from HBM once.
   const int wpu = 2 * a.n64 + a.n32;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
@@ -339,12 +406,30 @@ __global__ __launch_bounds__(512, 1) void conv_wino_kernel(const WArgs a) {
   const int uy = __builtin_amdgcn_readfirstlane((unit / a.nux) % a.nuy);
   const int img = __builtin_amdgcn_readfirstlane(unit / (a.nux * a.nuy));
   if (slot < 2 * a.n64) {
-    const int oy0 = uy * 16 + (slot & 1) * 8;
+    const int oy0 = uy * R::UH + (slot & 1) * (R::UH / 2);
     if (oy0 >= a.H) return;
-    wino_body<2, 2>(a, smem, img, oy0, ux * 32, (slot >> 1) * 64);
+    wino_body<2, R::TGA, SFT>(a, smem, img, oy0, ux * 32, (slot >> 1) * 64);
   } else {
-    wino_body<1, 4>(a, smem, img, uy * 16, ux * 32, a.n64 * 64);
+    wino_body<1, R::TGB, SFT>(a, smem, img, uy * R::UH, ux * 32, a.n64 * 64);
   }
+}
+
+template <bool NW8, bool SFT>
+int launch_wino(WArgs k, hipStream_t st) {
+  using R = Roles<NW8>;
+  static unsigned long long attr_done = 0;
+  auto kern = conv_wino_kernel<NW8, SFT>;
+  if (virnet::first_use_on_device(attr_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wino): %s", hipGetErrorString(e));
+  }
+  k.nux = (k.W + 31) / 32;
+  k.nuy = (k.H + R::UH - 1) / R::UH;
+  k.nunits = k.N * k.nux * k.nuy;
+  k.units_per_xcd = (k.nunits + 7) / 8;
+  const unsigned grid = (unsigned)(8 * k.units_per_xcd * (2 * k.n64 + k.n32));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW8 ? 512 : 256), R::LDS, st, k);
+  return virnet::check_launch("conv_wino launch");
 }
 
 // U = G g G^T of every (output channel, input channel) pair, in the chunk-stage layout the kernel copies linearly.
@@ -413,15 +498,12 @@ extern "C" int virnet_conv_wino(const virnet_conv_desc* d, void* stream) {
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.Cout = d->cout;
   k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
   k.n64 = d->cout / 64; k.n32 = (d->cout % 64) / 32;
-  k.nux = (d->w + 31) / 32; k.nuy = (d->h + 15) / 16;
-  k.nunits = d->n * k.nux * k.nuy;
-  k.units_per_xcd = (k.nunits + 7) / 8;
-  static unsigned long long attr_done = 0;
-  if (virnet::first_use_on_device(attr_done)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWinoLds);
-    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wino): %s", hipGetErrorString(e));
-  }
-  const unsigned grid = (unsigned)(8 * k.units_per_xcd * (2 * k.n64 + k.n32));
-  hipLaunchKernelGGL(conv_wino_kernel, dim3(grid), dim3(512), kWinoLds, static_cast<hipStream_t>(stream), k);
-  return virnet::check_launch("conv_wino launch");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // 8-wave workgroups re-read the weight image half as often; the 4-wave form covers the CUs when the grid is small.
+  static const int forced = [] { const char* e = getenv("VIRNET_WINO_NW"); return e ? atoi(e) : 0; }();    // tuning knob
+  const long units16 = (long)d->n * ((d->w + 31) / 32) * ((d->h + 15) / 16) * (2 * k.n64 + k.n32);
+  const bool nw8 = forced ? forced == 8 : units16 >= 1024;
+  const bool sft = d->in_mul != nullptr;
+  if (nw8) return sft ? launch_wino<true, true>(k, st) : launch_wino<true, false>(k, st);
+  return sft ? launch_wino<false, true>(k, st) : launch_wino<false, false>(k, st);
 }
