@@ -94,6 +94,9 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int nch = a.Cin >> 2;
+#ifdef WINO_TIMING
+  const long long tbeg = clock64();
+#endif
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
   const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
@@ -202,12 +205,14 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   };
 
   constexpr int RAW0 = 0, V0 = K::RAWB, U0 = K::RAWB + K::VB;
-  // ---- prologue: chunks 0 and 1 of the pixels, chunk 0 of the weights; transform chunk 0
+  // ---- prologue: chunks 0 and 1 of the pixels into LDS (chunk 2 stays in registers: pixels are fetched two iterations before
+  // they are landed, so no iteration waits on its own loads), chunk 0 of the weights; transform chunk 0
+  f32x4 rrc[PPT];
   {
     dma_u(0, smem + U0);
     f32x4 r0[PPT], r1[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) { r0[k] = load_raw1(0, k); r1[k] = load_raw1(1, k); }
+    for (int k = 0; k < PPT; ++k) { r0[k] = load_raw1(0, k); r1[k] = load_raw1(1, k); rrc[k] = load_raw1(2, k); }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) { store_raw1(smem + RAW0, 0, k, r0[k]); store_raw1(smem + K::STAGE + RAW0, 1, k, r1[k]); }
   }
@@ -221,58 +226,134 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   __syncthreads();
 
   f32x2 fa1[4], fb1[4];                                        // fragments of positions 4..7, consumed one iteration later
+#ifdef WINO_TIMING
+  long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+  const long long tstart = tprev;
+#define TICK(i) { const long long tn = clock64(); tacc[i] += tn - tprev; tprev = tn; }
+#else
+#define TICK(i)
+#endif
   // One chunk (buffers B compile-time: the loop is unrolled by two so every LDS address is a loop-invariant base + immediate).
-  // A wave issues in order and blocks on the busy matrix pipe, so everything else is threaded BETWEEN its 16 MFMAs: each
-  // piece runs under the MFMA issued before it, and the two waves of a SIMD keep the pipe fed through each other's pieces.
+  // A wave issues in order and blocks on the busy matrix pipe.  Measured per-wave timelines (tools/wino_timing.py): with the same
+  // instruction order in both waves of a SIMD, both stage at the same time and both want the pipe at the same time.  So the two
+  // waves of a SIMD (w and w+4 of an 8-wave workgroup: different position halves) run COMPLEMENTARY orders -- one stages first and
+  // multiplies second, the other the reverse -- and meet at the barrier.  4-wave workgroups share their SIMDs with an independent
+  // workgroup; they thread the staging pieces between the MFMAs instead.
   auto iteration = [&](int c, auto bsel, auto first) {
     constexpr int B = decltype(bsel)::value;
     constexpr bool FIRST = decltype(first)::value;
     char* const st_cur = smem + B * K::STAGE;
     char* const st_nxt = smem + (B ^ 1) * K::STAGE;
-    const bool more1 = c + 1 < nch, more2 = c + 2 < nch;
+    const bool more1 = c + 1 < nch, more2 = c + 2 < nch, more3 = c + 3 < nch;
     f32x2 fa0[4], fb0[4];
-    f32x4 rr[PPT];
+    f32x4 rrn[PPT];
     f32x2 da[XP][4], db[XP][4];
-    if (!FIRST) mf(4, 0, fa1, fb1);
-    SB();
-    read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
-    SB();
-    if (!FIRST) mf(5, 0, fa1, fb1);
-    SB();
+    TICK(5)
+    if (NW == 8) {
+      auto issue_loads = [&]() {
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) rr[k] = load_raw1(more2 ? c + 2 : c, k);
-    if (more1) dma_u(c + 1, st_nxt + U0);
-    SB();
-    if (!FIRST) mf(6, 0, fa1, fb1);
-    SB();
-    xf_read1(st_nxt + RAW0, 0, da[0], db[0]);
-    SB();
-    if (!FIRST) mf(7, 0, fa1, fb1);
-    SB();
-    if (XP == 2) xf_read1(st_nxt + RAW0, XP - 1, da[XP - 1], db[XP - 1]);
-    SB();
-    if (!FIRST) { mf(4, 1, fa1, fb1); mf(5, 1, fa1, fb1); }
-    SB();
-    if (more1) xf_write1(st_nxt + V0, 0, da[0], db[0]);
-    SB();
-    if (!FIRST) { mf(6, 1, fa1, fb1); mf(7, 1, fa1, fb1); }
-    SB();
-    if (XP == 2 && more1) xf_write1(st_nxt + V0, XP - 1, da[XP - 1], db[XP - 1]);
-    SB();
-    mf(0, 0, fa0, fb0); mf(1, 0, fa0, fb0);
-    SB();
-    if (more2) store_raw1(st_cur + RAW0, c + 2, 0, rr[0]);
-    SB();
-    mf(2, 0, fa0, fb0);
-    SB();
-    if (PPT == 2 && more2) store_raw1(st_cur + RAW0, c + 2, PPT - 1, rr[PPT - 1]);
-    SB();
-    mf(3, 0, fa0, fb0);
-    SB();
-    read_frags(st_cur + U0, st_cur + V0, 1, fa1, fb1);
-    SB();
-    mf(0, 1, fa0, fb0); mf(1, 1, fa0, fb0); mf(2, 1, fa0, fb0); mf(3, 1, fa0, fb0);
-    SB();
+        for (int k = 0; k < PPT; ++k) rrn[k] = load_raw1(more3 ? c + 3 : c, k);
+        if (more1) dma_u(c + 1, st_nxt + U0);
+      };
+      auto staging = [&]() {
+#pragma unroll
+        for (int pass = 0; pass < XP; ++pass) xf_read1(st_nxt + RAW0, pass, da[pass], db[pass]);
+        SB();
+        TICK(7)
+        if (more2) {
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) store_raw1(st_cur + RAW0, c + 2, k, rrc[k]);
+        }
+        SB();
+        TICK(8)
+        if (more1) {
+#pragma unroll
+          for (int pass = 0; pass < XP; ++pass) xf_write1(st_nxt + V0, pass, da[pass], db[pass]);
+        }
+        SB();
+        TICK(9)
+      };
+      auto multiply = [&]() {
+        if (!FIRST) {
+#pragma unroll
+          for (int lp = 4; lp < 8; ++lp) mf(lp, 0, fa1, fb1);
+#pragma unroll
+          for (int lp = 4; lp < 8; ++lp) mf(lp, 1, fa1, fb1);
+        }
+        SB();
+        read_frags(st_cur + U0, st_cur + V0, 1, fa1, fb1);
+        SB();
+#pragma unroll
+        for (int lp = 0; lp < 4; ++lp) mf(lp, 0, fa0, fb0);
+#pragma unroll
+        for (int lp = 0; lp < 4; ++lp) mf(lp, 1, fa0, fb0);
+      };
+      read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
+      issue_loads();
+      SB();
+      if (ph == 0) staging();
+      SB();
+      TICK(0)
+      multiply();
+      SB();
+      TICK(1)
+      if (ph != 0) staging();
+      SB();
+      TICK(2)
+    } else {
+      if (!FIRST) mf(4, 0, fa1, fb1);
+      SB();
+      read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
+      SB();
+      if (!FIRST) mf(5, 0, fa1, fb1);
+      SB();
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) rrn[k] = load_raw1(more3 ? c + 3 : c, k);
+      if (more1) dma_u(c + 1, st_nxt + U0);
+      SB();
+      if (!FIRST) mf(6, 0, fa1, fb1);
+      SB();
+      xf_read1(st_nxt + RAW0, 0, da[0], db[0]);
+      SB();
+      if (!FIRST) mf(7, 0, fa1, fb1);
+      SB();
+      if (XP == 2) xf_read1(st_nxt + RAW0, XP - 1, da[XP - 1], db[XP - 1]);
+      SB();
+      TICK(0)
+      if (!FIRST) { mf(4, 1, fa1, fb1); mf(5, 1, fa1, fb1); }
+      SB();
+      if (more1) xf_write1(st_nxt + V0, 0, da[0], db[0]);
+      SB();
+      if (!FIRST) { mf(6, 1, fa1, fb1); mf(7, 1, fa1, fb1); }
+      SB();
+      if (XP == 2 && more1) xf_write1(st_nxt + V0, XP - 1, da[XP - 1], db[XP - 1]);
+      SB();
+      TICK(1)
+      mf(0, 0, fa0, fb0); mf(1, 0, fa0, fb0);
+      SB();
+      TICK(2)
+      if (more2) store_raw1(st_cur + RAW0, c + 2, 0, rrc[0]);
+      SB();
+      mf(2, 0, fa0, fb0);
+      SB();
+      if (PPT == 2 && more2) store_raw1(st_cur + RAW0, c + 2, PPT - 1, rrc[PPT - 1]);
+      SB();
+      mf(3, 0, fa0, fb0);
+      SB();
+      read_frags(st_cur + U0, st_cur + V0, 1, fa1, fb1);
+      SB();
+      TICK(3)
+      mf(0, 1, fa0, fb0); mf(1, 1, fa0, fb0); mf(2, 1, fa0, fb0); mf(3, 1, fa0, fb0);
+      SB();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) rrc[k] = rrn[k];
+    TICK(4)
+#ifdef WINO_TIMING
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TICK(6)
+#endif
     __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
@@ -283,6 +364,9 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
     iteration(c + 1, I0{}, std::false_type{});
   }
   iteration(nch - 1, I1{}, std::false_type{});
+#ifdef WINO_TIMING
+  const long long tloop = clock64();
+#endif
 
   // ---- epilogue.  Lane = tile (row tg*2 + l31/16, column l31%16); this wave finalises output row 2*trow + ph, pixels
   // 2*tcol + b; accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3) -> 16-B accesses.  The residual and bias loads
@@ -379,6 +463,15 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
       }
     }
   }
+#ifdef WINO_TIMING
+  __syncthreads();
+  if (lane == 0 && a.add) {      // probe builds: `add` carries a timing buffer, 12 x int64 per wave
+    long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.add)) + ((size_t)blockIdx.x * 8 + wave) * 16;
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    o[6] = tloop - tstart; o[7] = clock64() - tloop; o[8] = tstart - tbeg; o[9] = CB; o[10] = tacc[6]; o[11] = wave + 1;
+    o[12] = tacc[7]; o[13] = tacc[8]; o[14] = tacc[9];
+  }
+#endif
 }
 
 // NW8 = true: 8-wave workgroups (roles <2,2> / <1,4>, unit = 16 x 32 output pixels); false: 4-wave workgroups (<2,1> / <1,2>,
@@ -499,10 +592,10 @@ extern "C" int virnet_conv_wino(const virnet_conv_desc* d, void* stream) {
   k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
   k.n64 = d->cout / 64; k.n32 = (d->cout % 64) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // 8-wave workgroups re-read the weight image half as often; the 4-wave form covers the CUs when the grid is small.
-  static const int forced = [] { const char* e = getenv("VIRNET_WINO_NW"); return e ? atoi(e) : 0; }();    // tuning knob
-  const long units16 = (long)d->n * ((d->w + 31) / 32) * ((d->h + 15) / 16) * (2 * k.n64 + k.n32);
-  const bool nw8 = forced ? forced == 8 : units16 >= 1024;
+  // Two 4-wave workgroups per CU measure faster than one 8-wave workgroup at every network shape (independent workgroups fill
+  // each other's barrier / prologue / epilogue gaps); VIRNET_WINO_NW=8 selects the 8-wave form for A/B runs.
+  static const int forced = [] { const char* e = getenv("VIRNET_WINO_NW"); return e ? atoi(e) : 0; }();
+  const bool nw8 = forced == 8;
   const bool sft = d->in_mul != nullptr;
   if (nw8) return sft ? launch_wino<true, true>(k, st) : launch_wino<true, false>(k, st);
   return sft ? launch_wino<false, true>(k, st) : launch_wino<false, false>(k, st);
