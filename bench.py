@@ -213,7 +213,7 @@ def main():
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch") if (pmc or {}).get("kernel", "").startswith("conv_wino") == wino else None,
-                    "kernel": ("conv_wino_kernel (3x3 stride-1, %d channels)" % dom[1]) if wino else "conv_mfma_kernel<%d,%d,%d,%d>" % dom,
+                    "kernel": ("conv_wino_kernel<false,false,%d> (3x3 stride-1, %d channels)" % (dom[1] // 64 * 2 + dom[1] % 64 // 32, dom[1])) if wino else "conv_mfma_kernel<%d,%d,%d,%d>" % dom,
                     "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC of the direct 3x3 convolution, algorithmic: SURVEY.md 8d)",

@@ -280,3 +280,73 @@ def test_conv_tensor_beyond_4gib():
         assert torch.equal(ri[0], raw[i])
     ref = F.conv2d(F.leaky_relu(x[n - 1, :40, :40].permute(2, 0, 1)[None].cpu(), 0.2), cp.weight.detach().cpu(), cp.bias.detach().cpu(), padding=1)
     assert maxerr(raw[n - 1, :38, :38].permute(2, 0, 1).cpu(), ref[0, :, :38, :38] + x[n - 1, :38, :38].permute(2, 0, 1).cpu()) <= TOL
+
+
+# ---- Winograd F(2x2,3x3) form of the stride-1 3x3 conv (csrc/wino.hip) ----------------------------------------------------------
+def test_winograd_weight_image_is_G_g_Gt():
+    """virnet_pack_wino_weight: U = G g G^T per channel pair, forward and input-gradient (flipped, transposed) packings."""
+    cout, cin = 64, 32
+    w = rnd(cout, cin, 3, 3, seed=70)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    for dgrad in (False, True):
+        g = w.double().flip(2, 3).transpose(0, 1) if dgrad else w.double()          # [rows][k][3][3]
+        ref = torch.einsum("ia,rkab,jb->rkij", G, g, G).float()                       # [rows][k][4][4]
+        rows, ks = ref.shape[:2]
+        u = ops.pack_wino_weight(w.cuda(), dgrad=dgrad).cpu().view(rows // 32, ks // 4, 16, 2, 32, 2)
+        # [slab][chunk][pos][half][col][s]: row = slab*32+col, k = chunk*4 + half*2 + s
+        got = u.permute(0, 4, 1, 3, 5, 2).reshape(rows, ks, 4, 4)
+        assert maxerr(got, ref) <= 1e-6
+
+
+@pytest.mark.parametrize("nw", ["4", "8"])
+@pytest.mark.parametrize("c,h,w,n", [(64, 9, 33, 2), (96, 17, 70, 1), (192, 6, 31, 2), (288, 8, 32, 1), (160, 5, 7, 1), (32, 3, 2, 1)])
+def test_winograd_vs_direct_and_oracle(monkeypatch, nw, c, h, w, n):
+    """Both workgroup forms of the Winograd kernel against the direct MFMA kernel and the CPU oracle: odd sizes (partial tiles and
+    units), every channel-block mix (64: role A only, 32/160: role B present, 96/288: both), residual + dual store."""
+    monkeypatch.setenv("VIRNET_WINO_NW", nw)
+    cp = make_conv(c, c, seed=80)
+    x, res = rnd(n, c, h, w, seed=81), rnd(n, c, h, w, seed=82)
+    raw_ref, act_ref = cpu_ref.conv_fused(F.leaky_relu(x, 0.2), cp.weight.detach(), cp.bias.detach(), residual=res, slope=0.25)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.wino is not None
+    kw = dict(in_slope=0.2, res=nhwc(res), want_raw=True, want_act=True, slope=0.25)
+    raw_w, act_w = ops.conv_mfma(nhwc(x), pw, **kw)
+    monkeypatch.setenv("VIRNET_WINOGRAD", "0")
+    raw_d, act_d = ops.conv_mfma(nhwc(x), pw, **kw)
+    assert maxerr(nchw(raw_w), raw_ref) <= TOL and maxerr(nchw(act_w), act_ref) <= TOL
+    assert maxerr(nchw(raw_d), raw_ref) <= TOL
+    assert maxerr(raw_w.cpu(), raw_d.cpu()) <= TOL
+
+
+def test_winograd_backward_epilogue_and_dgrad_packing():
+    """Input gradient of a res-block conv through the Winograd kernel: dgrad packing + LeakyReLU-derivative mask + residual add."""
+    c, n, h, w = 96, 2, 10, 37
+    cp = make_conv(c, c, seed=90)
+    dy, saved, skip = rnd(n, c, h, w, seed=91), rnd(n, c, h, w, seed=92), rnd(n, c, h, w, seed=93)
+    ref = F.conv_transpose2d(dy, cp.weight.detach(), padding=1) * torch.where(saved > 0, 1.0, 0.2) + skip
+    cp.cuda()
+    pw = cp.packed_dgrad()
+    assert pw.wino is not None
+    dx, _ = ops.conv_mfma(nhwc(dy), pw, mask=nhwc(saved), mask_slope=0.2, res=nhwc(skip), want_raw=True)
+    assert maxerr(nchw(dx), ref) <= TOL
+
+
+def test_winograd_abi_rejects_bad_descriptors():
+    cp = make_conv(64, 64).cuda()
+    pw = cp.packed()
+    x = torch.zeros(1, 4, 4, 64, device="cuda")
+    y = torch.empty(1, 4, 4, 64, device="cuda")
+    import ctypes as C
+    def desc(**over):
+        d = dict(x=nat.ptr(x), wpack=nat.ptr(pw.wino), bias=0, res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0, y_raw=nat.ptr(y),
+                 y_act=0, n=1, h=4, w=4, cin_pad=64, cout=64, n_pad=64, nrep=1, ks=3, stride=1, epi=nat.EPI_NHWC, nchw_op=0, crop_h=0, crop_w=0,
+                 res_sf=1, in_act=0, in_slope=0.0, slope=0.0, clamp_lo=0.0, clamp_hi=0.0)
+        d.update(over)
+        return nat.ConvDesc(**d)
+    lib = nat.load()
+    assert lib.virnet_conv_wino(C.byref(desc()), nat.stream_handle()) == 0
+    for bad in (dict(stride=2), dict(ks=1), dict(cout=48, n_pad=48), dict(epi=nat.EPI_NCHW), dict(y_raw=0), dict(cin_pad=24), dict(in_mul=nat.ptr(x))):
+        assert lib.virnet_conv_wino(C.byref(desc(**bad)), nat.stream_handle()) != 0, bad
+        assert lib.virnet_last_error()
+    torch.cuda.synchronize()

@@ -485,11 +485,14 @@ struct Roles {
   static constexpr int LDS = (Cfg<2, TGA>::LDS > Cfg<1, TGB>::LDS) ? Cfg<2, TGA>::LDS : Cfg<1, TGB>::LDS;
 };
 
-template <bool NW8, bool SFT>
+// WPU = workgroups per unit (2*n64 + n32) as a compile-time constant for the network's channel counts (64: 2, 96: 3, 192: 6,
+// 288: 9), 0 = read it from the arguments.  Besides the cheaper index arithmetic it gives each layer width its own kernel symbol,
+// so rocprofv3's per-kernel averages line up with bench.py's per-width HIP-event groups.
+template <bool NW8, bool SFT, int WPU>
 __global__ __launch_bounds__(NW8 ? 512 : 256, NW8 ? 1 : 2) void conv_wino_kernel(const WArgs a) {
   using R = Roles<NW8>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wpu = 2 * a.n64 + a.n32;
+  const int wpu = WPU ? WPU : 2 * a.n64 + a.n32;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
   const int slot = __builtin_amdgcn_readfirstlane(q % wpu);
@@ -507,11 +510,11 @@ __global__ __launch_bounds__(NW8 ? 512 : 256, NW8 ? 1 : 2) void conv_wino_kernel
   }
 }
 
-template <bool NW8, bool SFT>
+template <bool NW8, bool SFT, int WPU>
 int launch_wino(WArgs k, hipStream_t st) {
   using R = Roles<NW8>;
   static unsigned long long attr_done = 0;
-  auto kern = conv_wino_kernel<NW8, SFT>;
+  auto kern = conv_wino_kernel<NW8, SFT, WPU>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R::LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wino): %s", hipGetErrorString(e));
@@ -594,9 +597,16 @@ extern "C" int virnet_conv_wino(const virnet_conv_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   // Two 4-wave workgroups per CU measure faster than one 8-wave workgroup at every network shape (independent workgroups fill
   // each other's barrier / prologue / epilogue gaps); VIRNET_WINO_NW=8 selects the 8-wave form for A/B runs.
-  static const int forced = [] { const char* e = getenv("VIRNET_WINO_NW"); return e ? atoi(e) : 0; }();
-  const bool nw8 = forced == 8;
+  const char* const env_nw = getenv("VIRNET_WINO_NW");        // read per call (tests flip it)
+  const bool nw8 = env_nw && atoi(env_nw) == 8;
   const bool sft = d->in_mul != nullptr;
-  if (nw8) return sft ? launch_wino<true, true>(k, st) : launch_wino<true, false>(k, st);
-  return sft ? launch_wino<false, true>(k, st) : launch_wino<false, false>(k, st);
+  if (nw8) return sft ? launch_wino<true, true, 0>(k, st) : launch_wino<true, false, 0>(k, st);
+  if (sft) return launch_wino<false, true, 0>(k, st);
+  switch (2 * k.n64 + k.n32) {
+    case 2: return launch_wino<false, false, 2>(k, st);
+    case 3: return launch_wino<false, false, 3>(k, st);
+    case 6: return launch_wino<false, false, 6>(k, st);
+    case 9: return launch_wino<false, false, 9>(k, st);
+    default: return launch_wino<false, false, 0>(k, st);
+  }
 }
