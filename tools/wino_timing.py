@@ -37,4 +37,4 @@ for role in (2, 1):
         per = [m[i].item() / nch for i in (5, 0, 1, 2, 3, 4, 10)]
         print(f"{name} CB={role} wave {wv - 1}: {len(r)} wgs; per chunk: barrier {per[0]:.0f} | q1+pieces {per[1]:.0f} | q2+xfw {per[2]:.0f} | "
               f"m8,9 {per[3]:.0f} | store+m10,11+frag {per[4]:.0f} | q4 {per[5]:.0f} | waitcnt {per[6]:.0f} | sum {sum(per):.0f} ; prologue {m[8].item():.0f} "
-              f"loop {m[6].item():.0f} epilogue {m[7].item():.0f} | staging: xf_read {m[12].item() / nch:.0f} store_raw {m[13].item() / nch:.0f} xf_write {m[14].item() / nch:.0f}")
+              f"loop {m[6].item():.0f} epilogue {m[7].item():.0f} | epilogue: last MFMAs+loads {m[12].item():.0f} transform+exchange write {m[13].item():.0f} barrier {m[14].item():.0f} combine+stores {m[15].item():.0f}")

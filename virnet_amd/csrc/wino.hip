@@ -76,7 +76,8 @@ struct Cfg {
   static constexpr int UB = 32 * UROW;
   static constexpr int STAGE = RAWB + VB + UB;
   static constexpr int XCH = NW * 8192;             // result exchange: 8 KB per wave
-  static constexpr int LDS = (2 * STAGE > XCH) ? 2 * STAGE : XCH;
+  static constexpr int TURN = OHT * 32 * (CB * 128 + 16);   // epilogue turn-around buffer [pixel][CB*32 channels + 16 B]
+  static constexpr int LDS = (2 * STAGE > XCH + TURN) ? 2 * STAGE : XCH + TURN;
 };
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
@@ -102,7 +103,8 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
 
   // ---- pixel staging: thread -> pixel(s) of the halo tile.  Loads are always issued from a clamped address; out-of-image
   // pixels become zero on their way into LDS (after the activation: the conv pads the ACTIVATED tensor).
-  int poff[PPT], pdst[PPT];
+  unsigned poff[PPT];
+  int pdst[PPT];
   bool pinb[PPT];
   float pmsk[PPT];
 #pragma unroll
@@ -115,13 +117,13 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
     pinb[k] = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     pmsk[k] = pinb[k] ? 1.f : 0.f;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
-    poff[k] = (gyc * a.W + gxc) * a.Cin;
+    poff[k] = (unsigned)((gyc * a.W + gxc) * a.Cin);
     pdst[k] = has ? ((iy * 2 + (ix & 1)) * 17 + (ix >> 1)) * 16 : -1;
   }
   const float* const imul = SFT ? a.in_mul + (size_t)img * a.Cin : nullptr;
   const float* const iadd = SFT ? a.in_add + (size_t)img * a.Cin : nullptr;
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
-  auto load_raw1 = [&](int chunk, int k) -> f32x4 { return *reinterpret_cast<const f32x4*>(ximg + poff[k] + chunk * 4); };
+  auto load_raw1 = [&](int chunk, int k) -> f32x4 { return *reinterpret_cast<const f32x4*>(ximg + chunk * 4 + poff[k]); };
   // lrelu(x*mul+add) then zero outside the image.  Without SFT the image mask is folded into the multiply: lrelu(0) == 0.
   auto store_raw1 = [&](char* dstb, int chunk, int k, f32x4 r) {
     f32x4 v;
@@ -137,20 +139,22 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   };
   // ---- weight staging: 1-KB piece q of the chunk image [pos*2+half][CB*32 ch][8 B] <- packed [slab][chunk][pos*2+half][32][2].
   // The DMA writes LDS at (wave-uniform base) + lane*16, so lane l of piece q supplies the global address of byte q*1024 + l*16.
-  int uoff[UPW];
+  unsigned uoff[UPW];
 #pragma unroll
   for (int k = 0; k < UPW; ++k) {
     const int q16 = (wave * UPW + k) * 64 + lane;                // 16-B piece index within the chunk image
     const int row = q16 / (CB * 16), pc = q16 - row * (CB * 16);
     const int ch = pc * 2;                                     // channel pair within the CB*32 block
     const int slab = (cout_base >> 5) + (ch >> 5);
-    uoff[k] = slab * nch * 2048 + row * 64 + (ch & 31) * 2;
+    uoff[k] = (unsigned)(slab * nch * 2048 + row * 64 + (ch & 31) * 2);
   }
+  auto dma_one = [&](int chunk, char* dstb, int k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.up + chunk * 2048 + uoff[k]),
+                                     (__attribute__((address_space(3))) void*)(dstb + (wave * UPW + k) * 1024), 16, 0, 0);
+  };
   auto dma_u = [&](int chunk, char* dstb) {
 #pragma unroll
-    for (int k = 0; k < UPW; ++k)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.up + uoff[k] + chunk * 2048),
-                                       (__attribute__((address_space(3))) void*)(dstb + (wave * UPW + k) * 1024), 16, 0, 0);
+    for (int k = 0; k < UPW; ++k) dma_one(chunk, dstb, k);
   };
   // ---- input transform: item = (tile, row i of B^T d B, k-half); i = wave%4 (uniform), lanes = (k-half, tile column, row parity)
   const int ti = wave & 3, tq = wave >> 2;
@@ -235,11 +239,10 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
 #define TICK(i)
 #endif
   // One chunk (buffers B compile-time: the loop is unrolled by two so every LDS address is a loop-invariant base + immediate).
-  // A wave issues in order and blocks on the busy matrix pipe.  Measured per-wave timelines (tools/wino_timing.py): with the same
-  // instruction order in both waves of a SIMD, both stage at the same time and both want the pipe at the same time.  So the two
-  // waves of a SIMD (w and w+4 of an 8-wave workgroup: different position halves) run COMPLEMENTARY orders -- one stages first and
-  // multiplies second, the other the reverse -- and meet at the barrier.  4-wave workgroups share their SIMDs with an independent
-  // workgroup; they thread the staging pieces between the MFMAs instead.
+  // A wave issues in order and blocks on the busy matrix pipe, so the staging pieces are threaded BETWEEN its 16 MFMAs: each piece
+  // runs under the MFMA issued before it, and the other wave of the SIMD (the other workgroup's, in the 4-wave form) feeds the
+  // pipe through the gaps.  (Tried and dropped for the 8-wave form: complementary orders for the two waves of a SIMD -- stage
+  // first / multiply first -- measured 12 % slower: the staging burst of four waves at once queues up in LDS.)
   auto iteration = [&](int c, auto bsel, auto first) {
     constexpr int B = decltype(bsel)::value;
     constexpr bool FIRST = decltype(first)::value;
@@ -250,58 +253,7 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
     f32x4 rrn[PPT];
     f32x2 da[XP][4], db[XP][4];
     TICK(5)
-    if (NW == 8) {
-      auto issue_loads = [&]() {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) rrn[k] = load_raw1(more3 ? c + 3 : c, k);
-        if (more1) dma_u(c + 1, st_nxt + U0);
-      };
-      auto staging = [&]() {
-#pragma unroll
-        for (int pass = 0; pass < XP; ++pass) xf_read1(st_nxt + RAW0, pass, da[pass], db[pass]);
-        SB();
-        TICK(7)
-        if (more2) {
-#pragma unroll
-          for (int k = 0; k < PPT; ++k) store_raw1(st_cur + RAW0, c + 2, k, rrc[k]);
-        }
-        SB();
-        TICK(8)
-        if (more1) {
-#pragma unroll
-          for (int pass = 0; pass < XP; ++pass) xf_write1(st_nxt + V0, pass, da[pass], db[pass]);
-        }
-        SB();
-        TICK(9)
-      };
-      auto multiply = [&]() {
-        if (!FIRST) {
-#pragma unroll
-          for (int lp = 4; lp < 8; ++lp) mf(lp, 0, fa1, fb1);
-#pragma unroll
-          for (int lp = 4; lp < 8; ++lp) mf(lp, 1, fa1, fb1);
-        }
-        SB();
-        read_frags(st_cur + U0, st_cur + V0, 1, fa1, fb1);
-        SB();
-#pragma unroll
-        for (int lp = 0; lp < 4; ++lp) mf(lp, 0, fa0, fb0);
-#pragma unroll
-        for (int lp = 0; lp < 4; ++lp) mf(lp, 1, fa0, fb0);
-      };
-      read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
-      issue_loads();
-      SB();
-      if (ph == 0) staging();
-      SB();
-      TICK(0)
-      multiply();
-      SB();
-      TICK(1)
-      if (ph != 0) staging();
-      SB();
-      TICK(2)
-    } else {
+    {
       if (!FIRST) mf(4, 0, fa1, fb1);
       SB();
       read_frags(st_cur + U0, st_cur + V0, 0, fa0, fb0);
@@ -310,18 +262,24 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
       SB();
 #pragma unroll
       for (int k = 0; k < PPT; ++k) rrn[k] = load_raw1(more3 ? c + 3 : c, k);
-      if (more1) dma_u(c + 1, st_nxt + U0);
+      if (more1) dma_one(c + 1, st_nxt + U0, 0);
       SB();
       if (!FIRST) mf(6, 0, fa1, fb1);
       SB();
       xf_read1(st_nxt + RAW0, 0, da[0], db[0]);
+      if (UPW >= 2 && more1) dma_one(c + 1, st_nxt + U0, UPW >= 2 ? 1 : 0);
       SB();
       if (!FIRST) mf(7, 0, fa1, fb1);
       SB();
       if (XP == 2) xf_read1(st_nxt + RAW0, XP - 1, da[XP - 1], db[XP - 1]);
+      if (UPW == 4 && more1) dma_one(c + 1, st_nxt + U0, UPW - 2);
       SB();
       TICK(0)
-      if (!FIRST) { mf(4, 1, fa1, fb1); mf(5, 1, fa1, fb1); }
+      if (!FIRST) mf(4, 1, fa1, fb1);
+      SB();
+      if (UPW == 4 && more1) dma_one(c + 1, st_nxt + U0, UPW - 1);
+      SB();
+      if (!FIRST) mf(5, 1, fa1, fb1);
       SB();
       if (more1) xf_write1(st_nxt + V0, 0, da[0], db[0]);
       SB();
@@ -366,44 +324,51 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
   iteration(nch - 1, I1{}, std::false_type{});
 #ifdef WINO_TIMING
   const long long tloop = clock64();
+  long long te[5] = {0, 0, 0, 0, 0};
+#define ETICK(i) te[i] = clock64();
+#else
+#define ETICK(i)
 #endif
 
-  // ---- epilogue.  Lane = tile (row tg*2 + l31/16, column l31%16); this wave finalises output row 2*trow + ph, pixels
-  // 2*tcol + b; accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3) -> 16-B accesses.  The residual and bias loads
-  // are issued before the last MFMAs and the exchange so their latency is covered.
+  // ---- epilogue.  Accumulator side: lane = tile (row tg*2 + l31/16, column l31%16); this wave finalises output row 2*trow + ph,
+  // pixels 2*tcol + b; accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3).  Stored that way a wave instruction
+  // would write 64 separate 16-B pieces (measured: the stores of one tile took ~6k cycles to issue), so the finished tile is
+  // turned around in LDS ([pixel][CB*32 channels], 16 B of padding per pixel against bank conflicts) and every thread handles
+  // (pixel, channel quad) pieces: 16 (8) consecutive lanes cover one pixel's 256 (128) contiguous bytes in the residual / mask
+  // loads and in the stores.  Those loads are issued before the last MFMAs so the exchange covers their latency.
   const int C = a.Cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
   const float* const rimg = a.res ? a.res + img_off : nullptr;
   const float* const mimg = a.mask ? a.mask + img_off : nullptr;
   float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
   float* const yact = a.y_act ? a.y_act + img_off : nullptr;
-  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
-  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
-  const int oy = oy0 + 2 * (tg * 2 + (l31 >> 4)) + ph;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  unsigned eo[2];
-  bool ok[2];
+  constexpr int QPP = CB * 8;                        // channel quads per pixel in this workgroup's channel block
+  constexpr int TPIX = CB * 128 + 16;                // bytes per pixel in the turn-around buffer
+  constexpr int EPT = (K::OHT * 32 * QPP) / NT;      // pieces per thread (= 8)
+  static_assert((K::OHT * 32 * QPP) % NT == 0 && NT % QPP == 0, "epilogue piece mapping");
+  const int ecq = tid % QPP;                         // this thread's channel quad (the same for all its pieces)
+  const int eco = cout_base + ecq * 4;
+  unsigned eoff[EPT];
+  bool eok[EPT];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int ox = ox0 + 2 * (l31 & 15) + b;
-    ok[b] = oy < a.H && ox < a.W;
-    eo[b] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C;
+  for (int k = 0; k < EPT; ++k) {
+    const int pix = (k * NT + tid) / QPP;            // pixel within the workgroup tile, row-major 32 wide
+    const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+    eok[k] = oy < a.H && ox < a.W;
+    eoff[k] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)eco;
   }
-  f32x4 bias[4], rv[4][2];
-  int cog[4];
+  const f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + eco) : zero4;
+  f32x4 rv[EPT];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    cog[g] = cout_base + cbw * 32 + 8 * g + 4 * lhi;
-    bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + cog[g]) : zero4;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) rv[g][b] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eo[b] + cog[g]) : zero4;
-  }
+  for (int k = 0; k < EPT; ++k) rv[k] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eoff[k]) : zero4;
   SB();
 #pragma unroll
   for (int lp = 4; lp < 8; ++lp) mf(lp, 0, fa1, fb1);
 #pragma unroll
   for (int lp = 4; lp < 8; ++lp) mf(lp, 1, fa1, fb1);
 
+  ETICK(0)
   // output transform.  acc[lp], lp = i*2 + jj, holds M[i][2*ph+jj].  T[a][jj] = (A^T M)[a][j]; the pair's halves of
   // Y[a][b] = sum_j T[a][j] A[j][b] are  ph 0: {T0+T1, T1}   ph 1: {T2, -T2-T3}.  This wave finalises output row a = ph.
   f32x16 keep[2], send[2];
@@ -431,45 +396,60 @@ __device__ __forceinline__ void wino_body(const WArgs& a, char* const smem, cons
         *reinterpret_cast<f32x4*>(mine + (b * 4 + g) * 1024) =
             f32x4{send[b][4 * g], send[b][4 * g + 1], send[b][4 * g + 2], send[b][4 * g + 3]};
   }
+  ETICK(1)
   __syncthreads();
-  const char* const theirs = smem + (wave ^ (CB * TG)) * 8192 + lane * 16;
-  f32x4 mv[4][2], yv[4][2];
+  ETICK(2)
+  {
+    const char* const theirs = smem + (wave ^ (CB * TG)) * 8192 + lane * 16;
+    char* const tbuf = smem + K::XCH;
+    const int prow = 2 * (tg * 2 + (l31 >> 4)) + ph;           // output row within the workgroup tile
+    char* const tdst = tbuf + (prow * 32 + 2 * (l31 & 15)) * TPIX + (cbw * 32 + 4 * lhi) * 4;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      if (mimg) mv[g][b] = *reinterpret_cast<const f32x4*>(mimg + eo[b] + cog[g]);
-      yv[g][b] = *reinterpret_cast<const f32x4*>(theirs + (b * 4 + g) * 1024);
-    }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(theirs + (b * 4 + g) * 1024) +
+                        f32x4{keep[b][4 * g], keep[b][4 * g + 1], keep[b][4 * g + 2], keep[b][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(tdst + b * TPIX + g * 32) = y;
+      }
+  }
+  __syncthreads();
+  {
+    const char* const tsrc = smem + K::XCH + ecq * 16;
     f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
-    if (mulp) {
-      mul = *reinterpret_cast<const f32x4*>(mulp + cog[g]);
-      add = *reinterpret_cast<const f32x4*>(addp + cog[g]);
+    if (a.mul) {
+      mul = *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + eco);
+      add = *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + eco);
+    }
+    f32x4 mv[EPT];
+    if (mimg) {
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) mv[k] = *reinterpret_cast<const f32x4*>(mimg + eoff[k]);
     }
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      f32x4 v = yv[g][b] + f32x4{keep[b][4 * g], keep[b][4 * g + 1], keep[b][4 * g + 2], keep[b][4 * g + 3]} + bias[g];
+    for (int k = 0; k < EPT; ++k) {
+      const int pix = (k * NT + tid) / QPP;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tsrc + pix * TPIX) + bias4;
       if (mimg) {
-        const f32x4 m = mv[g][b];
+        const f32x4 m = mv[k];
         v = f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
                   m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
       }
-      v += rv[g][b];
-      if (ok[b]) {
-        if (yraw) *reinterpret_cast<f32x4*>(yraw + eo[b] + cog[g]) = v;
-        if (yact) *reinterpret_cast<f32x4*>(yact + eo[b] + cog[g]) = lrelu4(v * mul + add, a.slope);
+      v += rv[k];
+      if (eok[k]) {
+        if (yraw) *reinterpret_cast<f32x4*>(yraw + eoff[k]) = v;
+        if (yact) *reinterpret_cast<f32x4*>(yact + eoff[k]) = lrelu4(v * mul + add, a.slope);
       }
     }
   }
 #ifdef WINO_TIMING
+  ETICK(3)
   __syncthreads();
   if (lane == 0 && a.add) {      // probe builds: `add` carries a timing buffer, 12 x int64 per wave
     long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.add)) + ((size_t)blockIdx.x * 8 + wave) * 16;
     for (int i = 0; i < 6; ++i) o[i] = tacc[i];
     o[6] = tloop - tstart; o[7] = clock64() - tloop; o[8] = tstart - tbeg; o[9] = CB; o[10] = tacc[6]; o[11] = wave + 1;
-    o[12] = tacc[7]; o[13] = tacc[8]; o[14] = tacc[9];
+    o[12] = te[0] - tloop; o[13] = te[1] - te[0]; o[14] = te[2] - te[1]; o[15] = te[3] - te[2];
   }
 #endif
 }
