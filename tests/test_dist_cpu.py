@@ -53,3 +53,48 @@ def test_weight_broadcast_and_gather_world2():
     assert not r0["changed"] and r1["changed"] and r1["bumped"]       # rank 1 received rank 0's values, in place
     assert r0["full"] == r1["full"] == [0.0, 10.0, 20.0, 30.0, 40.0]
     assert r0["tmax"] == r1["tmax"] == 2.0
+
+
+def _reducer_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init(backend="gloo")
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300,), (40, 10), (7,), (1000,), (3, 3))]
+    frozen = torch.nn.Parameter(torch.zeros(5), requires_grad=False)
+    red = vdist.GradientReducer(params + [frozen], bucket_bytes=2000)          # 500 floats per bucket
+    steps = []
+    for step in range(3):
+        red.start()
+        order = [4, 2, 0, 3] if step < 2 else [0, 4, 2, 3]                       # parameter 1 never produces a gradient; order may change
+        for i in order:
+            red.push({params[i]: torch.full(params[i].shape, float((rank + 1) * (i + 1) + step))})
+        out = red.finish()
+        steps.append({i: float(out[params[i]].reshape(-1)[0]) for i in range(5)})
+        assert all(out[p].shape == p.shape for p in params) and frozen not in out
+        assert all(torch.all(out[params[i]] == out[params[i]].reshape(-1)[0]) for i in range(5))
+    ret[rank] = dict(steps=steps, buckets=red.bucket_sizes)
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_buckets_average_world2():
+    """Bucketed asynchronous averaging: mean over ranks, zeros for parameters without a gradient, layout fixed by the
+    first step's production order, later steps reduce bucket by bucket as they fill."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_reducer_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] == ret[1]
+    assert ret[0]["buckets"] == [316, 1000, 400]          # (9 + 7 + 300) | 1000 | the parameter never produced (400), last
+    for step, got in enumerate(ret[0]["steps"]):
+        for i in range(5):
+            want = 0.0 if i == 1 else (1 * (i + 1) + step + 2 * (i + 1) + step) / 2.0
+            assert got[i] == want, (step, i, got[i], want)
+
+
+def test_gradient_reducer_single_process_is_identity():
+    p = [torch.nn.Parameter(torch.zeros(4, 4)), torch.nn.Parameter(torch.zeros(3))]
+    red = vdist.GradientReducer(p)
+    for _ in range(2):
+        red.start()
+        red.push({p[1]: torch.arange(3.0)})
+        red.push({p[0]: torch.ones(4, 4)})
+        out = red.finish()
+        assert torch.equal(out[p[0]], torch.ones(4, 4)) and torch.equal(out[p[1]], torch.arange(3.0))

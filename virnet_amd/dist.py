@@ -1,4 +1,4 @@
-"""Multi-GPU inference plumbing: one process per GPU, images sharded, weights broadcast once.
+"""Multi-GPU plumbing: one process per GPU, images sharded, weights broadcast once; for training, bucketed gradient averaging.
 
 The path shards by independent images (no batch statistics, no cross-sample op -- SURVEY.md 8e), so the only collective
 is ONE flat fp32 weight broadcast at start-up (42 MB for the denoise-syn net).  On ROCm ``backend="nccl"`` is RCCL; on the
@@ -7,7 +7,7 @@ fully connected xGMI mesh rank 0 feeds its 7 peers over 7 distinct links.  There
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -82,3 +82,122 @@ def gather_shards(local: torch.Tensor, total: int) -> Optional[torch.Tensor]:
     outs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(outs, pad)
     return torch.cat([o[: b - a] for o, (a, b) in zip(outs, sizes)], 0)
+
+
+class GradientReducer:
+    """Bucketed, asynchronous gradient averaging for the training step (the job DistributedDataParallel does at
+    ``train_denoising_syn.py:71``, shaped for this path).
+
+    The whole network is ONE autograd Function here, so torch's per-parameter hooks would all fire at the end of the backward and
+    nothing would overlap.  Instead the backward hands every layer's gradients to ``push`` as soon as its wgrad kernels are
+    queued; they are scaled by 1/world into a flat fp32 bucket and a bucket is all-reduced (``async_op=True``: RCCL runs it on its
+    own stream behind the work already queued) while the remaining layers' dgrad/wgrad kernels execute.  ``finish`` waits and returns
+    bucket VIEWS as the gradients (no copy back).  Buckets are laid out in the order the first backward produced the gradients.
+    On the xGMI mesh the 42 MB of denoise-syn gradients are 6 buckets of <= 8 MB; RCCL chooses the algorithm per message.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 8 << 20, group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.bucket_bytes = int(bucket_bytes)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._order: List[torch.nn.Parameter] = []          # production order seen during the first step
+        self._slots: Optional[Dict[int, Tuple[int, int, int]]] = None   # id(param) -> (bucket, offset, numel)
+        self._buckets: List[torch.Tensor] = []
+        self._remaining: List[int] = []
+        self._members: List[int] = []
+        self._works: list = []
+        self._first: Dict[int, torch.Tensor] = {}
+
+    # -- bucket layout ------------------------------------------------------------------------------------------------
+    def _build(self, device: torch.device) -> None:
+        known = {id(p) for p in self._order}
+        order = self._order + [p for p in self.params if id(p) not in known]      # never-produced parameters go last
+        self._slots, sizes = {}, []
+        cur, used = 0, 0
+        for p in order:
+            n = p.numel()
+            if used and (used + n) * 4 > self.bucket_bytes:
+                sizes.append(used)
+                cur, used = cur + 1, 0
+            self._slots[id(p)] = (cur, used, n)
+            used += n
+        sizes.append(used)
+        self._buckets = [torch.zeros(n, dtype=torch.float32, device=device) for n in sizes]
+        self._members = [0] * len(sizes)
+        for b, _, _ in self._slots.values():
+            self._members[b] += 1
+
+    @property
+    def bucket_sizes(self) -> List[int]:
+        return [int(b.numel()) for b in self._buckets]
+
+    # -- per step -----------------------------------------------------------------------------------------------------
+    def start(self) -> None:
+        self._works = []
+        self._first = {}
+        if self._slots is not None:
+            self._remaining = list(self._members)
+            for b in self._buckets:
+                b.zero_()
+
+    def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> None:
+        scale = 1.0 / self.world
+        for p, g in grads.items():
+            if g is None or not p.requires_grad:
+                continue
+            if self._slots is None:                       # first step: record the order, reduce everything in finish()
+                self._order.append(p)
+                self._first[id(p)] = g
+                continue
+            b, off, n = self._slots[id(p)]
+            self._buckets[b][off:off + n].copy_(g.reshape(-1)).mul_(scale)
+            self._remaining[b] -= 1
+            if self._remaining[b] == 0 and self.world > 1:
+                self._works.append(dist.all_reduce(self._buckets[b], group=self.group, async_op=True))
+
+    def finish(self) -> Dict[torch.nn.Parameter, torch.Tensor]:
+        if self._slots is None:                           # first step: lay the buckets out, then one synchronous pass
+            dev = next(iter(self._first.values())).device if self._first else self.params[0].device
+            self._build(dev)
+            first = self._first
+            self.start()
+            scale = 1.0 / self.world
+            for p in self.params:
+                g = first.get(id(p))
+                if g is not None:
+                    b, off, n = self._slots[id(p)]
+                    self._buckets[b][off:off + n].copy_(g.reshape(-1)).mul_(scale)
+            if self.world > 1:
+                self._works = [dist.all_reduce(bk, group=self.group, async_op=True) for bk in self._buckets]
+        elif self.world > 1:
+            for b, left in enumerate(self._remaining):    # buckets holding parameters nobody produced this step
+                if left > 0:
+                    self._works.append(dist.all_reduce(self._buckets[b], group=self.group, async_op=True))
+        for w in self._works:
+            w.wait()
+        self._works = []
+        out = {}
+        for p in self.params:
+            b, off, n = self._slots[id(p)]
+            out[p] = self._buckets[b][off:off + n].view_as(p)
+        return out
+
+
+class DistributedTrainer(torch.nn.Module):
+    """``DistributedDataParallel``-shaped wrapper for the drop-in modules: broadcasts rank 0's parameters once, then averages the
+    gradients of every backward through a :class:`GradientReducer` that overlaps the collectives with the backward kernels.
+
+        net = DistributedTrainer(VIRAttResUNet(...).cuda(rank))      # train_denoising_syn.py:71
+        mu, sigma = net(x); loss.backward(); optimizer.step()
+    """
+
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 8 << 20, group=None):
+        super().__init__()
+        self.module = module
+        broadcast_parameters(module, src=0, group=group)
+        self.reducer = GradientReducer(module.parameters(), bucket_bytes=bucket_bytes, group=group)
+        module._grad_reducer = self.reducer
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -93,14 +93,17 @@ def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
 
 
 def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1, in_slope: Optional[float] = None,
-                cvalid: Optional[int] = None) -> None:
-    """dW, db of one conv from its forward input and output gradient (NHWC)."""
-    grads[conv.weight] = ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)
+                cvalid: Optional[int] = None, reducer=None) -> None:
+    """dW, db of one conv from its forward input and output gradient (NHWC); handed to the gradient reducer at once (DDP runs)."""
+    new = {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
     if conv.bias is not None:
-        grads[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+        new[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+    grads.update(new)
+    if reducer is not None:
+        reducer.push(new)
 
 
-def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[Tensor]) -> Dict:
+def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[Tensor], reducer=None) -> Dict:
     snet, rnet = net.SNet, net.RNet
     grads: Dict = {}
     h, w = tape.misc["hw"]
@@ -112,30 +115,32 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
         dmu = dmu.detach().contiguous()
         # ---- tail: mu = conv(x_last)[crop] + x_in  (AttResUNet.py:173)
         g16 = ops.pack_input(dmu, hp, wp, zero_pad=True)                       # gradient record, zero beyond the crop
-        _conv_grads(grads, rnet.tail, tape.misc["x_last"], g16)
+        _conv_grads(grads, rnet.tail, tape.misc["x_last"], g16, reducer=reducer)
         dx, _ = ops.conv_mfma(g16, rnet.tail.packed_dgrad(), want_raw=True)
         nb = tape.misc["nbridges"]
         dbridge: List[Optional[Tensor]] = [None] * nb
         for kind, mod, x_in, aux in reversed(tape.misc["order"]):
             if kind == "block":                                                 # AttResBlock, AttResUNet.py:48-60
                 f1a = aux
-                _conv_grads(grads, mod.conv2, f1a, dx)
+                _conv_grads(grads, mod.conv2, f1a, dx, reducer=reducer)
                 d_f1, _ = ops.conv_mfma(dx, mod.conv2.packed_dgrad(), mask=f1a, mask_slope=0.2, want_raw=True)
-                _conv_grads(grads, mod.conv1, x_in, d_f1, in_slope=0.2)
+                _conv_grads(grads, mod.conv1, x_in, d_f1, in_slope=0.2, reducer=reducer)
                 dx, _ = ops.conv_mfma(d_f1, mod.conv1.packed_dgrad(), mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
             elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
                 dbridge[aux] = dx
                 s2d = ops.space_to_depth2(dx)
-                grads[mod.weight] = ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True)
-                grads[mod.bias] = ops.colsum(dx)
+                new = {mod.weight: ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True), mod.bias: ops.colsum(dx)}
+                grads.update(new)
+                if reducer is not None:
+                    reducer.push(new)
                 dx, _ = ops.conv_mfma(s2d, mod.packed_dgrad(), want_raw=True)
             else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
-                _conv_grads(grads, mod, x_in, dx, stride=2)
+                _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer)
                 nb -= 1
                 dx, _ = ops.conv_mfma(ops.zero_stuff2(dx), mod.packed_dgrad(), res=dbridge[nb], want_raw=True)
         # ---- head (AttResUNet.py:153-155): weights, and the gradient flowing into sqrt(sigma) through the conditioning channel
         rec = tape.misc["rec"]
-        _conv_grads(grads, rnet.head, rec, dx)
+        _conv_grads(grads, rnet.head, rec, dx, reducer=reducer)
         if tape.misc["cond"]:
             drec, _ = ops.conv_mfma(dx, rnet.head.packed_dgrad(), want_raw=True, out_channels=32)
             parts = [ops.pack_input_backward(drec, rnet.in_chn + c, (h, w), map_=sigma[:, c:c + 1].contiguous(), map_sqrt=True)
@@ -149,12 +154,12 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
     dv = (d_sigma_total * sigma * inside).contiguous()                           # few-channel map: host-side glue
     g16 = ops.pack_input(dv, h, w, zero_pad=True)
     acts, mids = tape.snet["acts"], tape.snet["mids"]
-    _conv_grads(grads, snet.conv_last, acts[-1], g16)
+    _conv_grads(grads, snet.conv_last, acts[-1], g16, reducer=reducer)
     dpre, _ = ops.conv_mfma(g16, snet.conv_last.packed_dgrad(), mask=acts[-1], mask_slope=0.25, want_raw=True)
     for k in range(len(mids) - 1, -1, -1):                                       # post-activation stack, DnCNN.py:25-28
-        _conv_grads(grads, mids[k], acts[k], dpre)
+        _conv_grads(grads, mids[k], acts[k], dpre, reducer=reducer)
         dpre, _ = ops.conv_mfma(dpre, mids[k].packed_dgrad(), mask=acts[k], mask_slope=0.25, want_raw=True)
-    _conv_grads(grads, snet.conv1, tape.snet["rec"], dpre)
+    _conv_grads(grads, snet.conv1, tape.snet["rec"], dpre, reducer=reducer)
     return grads
 
 
@@ -172,8 +177,13 @@ class DenoiseFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dmu, dsigma):
         dev = (dmu if dmu is not None else dsigma).device
+        reducer = getattr(ctx.net, "_grad_reducer", None)
         with torch.no_grad(), torch.cuda.device(dev):
-            grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma)
+            if reducer is not None:
+                reducer.start()
+            grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma, reducer=reducer)
+            if reducer is not None:
+                grads = reducer.finish()                  # averaged over the ranks; views of the flat buckets
         ctx.tape = None
         return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
