@@ -10,7 +10,7 @@ configs[2]'s 256).  ``--size 128 --batch 64`` runs configs[1].  Scaling is weak:
 collective is the start-up weight broadcast (RCCL), nothing is exchanged per image.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline     : the dominant kernel (the launch group of the C->C 3x3 res-block convs: conv_wino_kernel, or conv_mfma_kernel<3,1,2,3> with VIRNET_WINOGRAD=0) -- algorithmic FLOPs per launch / its
+  roofline     : the dominant kernel (the launch group of the C->C 3x3 res-block convs: conv_wino_row_kernel, or conv_mfma_kernel<3,1,2,3> with VIRNET_WINOGRAD=0) -- algorithmic FLOPs per launch / its
                  average launch duration, measured with HIP events recorded on the launch stream around every launch inside the
                  timed region (rank 0), against the 157.3 TFLOP/s fp32-MFMA peak
   cpu_baseline : the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores on a bounded sample.
@@ -213,7 +213,7 @@ def main():
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch") if (pmc or {}).get("kernel", "").startswith("conv_wino") == wino else None,
-                    "kernel": ("conv_wino_kernel<false,false,%d> (3x3 stride-1, %d channels)" % (dom[1] // 64 * 2 + dom[1] % 64 // 32, dom[1])) if wino else "conv_mfma_kernel<%d,%d,%d,%d>" % dom,
+                    "kernel": ("conv_wino_row_kernel<G,false,%d> (3x3 stride-1, %d channels; G = 1: 4-wave, 2: 8-wave workgroups)" % (dom[1] // 64 * 2 + dom[1] % 64 // 32, dom[1])) if wino else "conv_mfma_kernel<%d,%d,%d,%d>" % dom,
                     "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC of the direct 3x3 convolution, algorithmic: SURVEY.md 8d)",

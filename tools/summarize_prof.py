@@ -13,9 +13,9 @@ def short(name):
     m = re.search(r"conv_mfma_kernel<([^>]*)>", name)
     if m:
         return "conv_mfma_kernel<%s>" % m.group(1).replace("(anonymous namespace)::", "").replace(" ", "")
-    m = re.search(r"conv_wino_kernel<([^>]*)>", name)
+    m = re.search(r"(conv_wino\w*_kernel)<([^>]*)>", name)
     if m:
-        return "conv_wino_kernel<%s>" % m.group(1).replace(" ", "")
+        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     return re.sub(r"\(.*", "", name)[:80]
 
