@@ -350,3 +350,43 @@ def test_winograd_abi_rejects_bad_descriptors():
         assert lib.virnet_conv_wino(C.byref(desc(**bad)), nat.stream_handle()) != 0, bad
         assert lib.virnet_last_error()
     torch.cuda.synchronize()
+
+
+def test_winograd_randomised_sweep_against_direct_kernel(monkeypatch):
+    """Seeded sweep over shapes / channel mixes / epilogue options: the Winograd kernel (both workgroup forms) must agree with the
+    direct MFMA kernel run on the same tensors -- catches ordering bugs (buffer reuse, partial units) that fixed shapes can miss."""
+    g = np.random.Generator(np.random.Philox(key=[77, 3]))
+    chans = [32, 64, 96, 128, 160, 192, 224, 288]
+    worst = 0.0
+    for case in range(40):
+        cin, cout = int(g.choice(chans)), int(g.choice(chans))
+        n, h, w = int(g.integers(1, 4)), int(g.integers(1, 41)), int(g.integers(1, 75))
+        opts = dict(pre=bool(g.integers(0, 2)), res=bool(g.integers(0, 2)), mask=bool(g.integers(0, 2)), sft=bool(g.integers(0, 3) == 0),
+                    dual=bool(g.integers(0, 2)))
+        cp = make_conv(cin, cout, seed=200 + case).cuda()
+        x = nhwc(rnd(n, cin, h, w, seed=300 + case))
+        kw = dict(want_raw=True, want_act=opts["dual"], slope=0.2)
+        if opts["pre"] or opts["sft"]:
+            kw["in_slope"] = 0.2
+        if opts["sft"]:
+            kw.update(in_mul=rnd(n, cin, seed=400 + case, lo=0.3, hi=1.0).cuda(), in_add=rnd(n, cin, seed=500 + case).cuda(),
+                      mul=rnd(n, cout, seed=600 + case, lo=0.3, hi=1.0).cuda(), add=rnd(n, cout, seed=700 + case).cuda())
+        if opts["res"]:
+            kw["res"] = nhwc(rnd(n, cout, h, w, seed=800 + case))
+        if opts["mask"]:
+            kw.update(mask=nhwc(rnd(n, cout, h, w, seed=900 + case)), mask_slope=0.25)
+        monkeypatch.setenv("VIRNET_WINOGRAD", "1")
+        pw = cp.packed()
+        assert pw.wino is not None
+        outs = {}
+        for form in ("4", "8", "direct"):
+            monkeypatch.setenv("VIRNET_WINOGRAD", "0" if form == "direct" else "1")
+            monkeypatch.setenv("VIRNET_WINO_NW", form if form != "direct" else "4")
+            outs[form] = ops.conv_mfma(x, pw, **kw)
+        for form in ("4", "8"):
+            for a, b in zip(outs[form], outs["direct"]):
+                if a is not None:
+                    e = maxerr(a.cpu(), b.cpu())
+                    worst = max(worst, e)
+                    assert e <= 5e-5, (case, form, cin, cout, n, h, w, opts, e)
+    assert worst > 0.0            # the two algorithms are different roundings of the same sums
