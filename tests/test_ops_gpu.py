@@ -304,6 +304,7 @@ def test_winograd_vs_direct_and_oracle(monkeypatch, nw, c, h, w, n):
     """Both workgroup forms of the Winograd kernel against the direct MFMA kernel and the CPU oracle: odd sizes (partial tiles and
     units), every channel-block mix (64: role A only, 32/160: role B present, 96/288: both), residual + dual store."""
     monkeypatch.setenv("VIRNET_WINO_NW", nw)
+    monkeypatch.setenv("VIRNET_WINOGRAD", "1")
     cp = make_conv(c, c, seed=80)
     x, res = rnd(n, c, h, w, seed=81), rnd(n, c, h, w, seed=82)
     raw_ref, act_ref = cpu_ref.conv_fused(F.leaky_relu(x, 0.2), cp.weight.detach(), cp.bias.detach(), residual=res, slope=0.25)
@@ -319,8 +320,9 @@ def test_winograd_vs_direct_and_oracle(monkeypatch, nw, c, h, w, n):
     assert maxerr(raw_w.cpu(), raw_d.cpu()) <= TOL
 
 
-def test_winograd_backward_epilogue_and_dgrad_packing():
+def test_winograd_backward_epilogue_and_dgrad_packing(monkeypatch):
     """Input gradient of a res-block conv through the Winograd kernel: dgrad packing + LeakyReLU-derivative mask + residual add."""
+    monkeypatch.setenv("VIRNET_WINOGRAD", "1")
     c, n, h, w = 96, 2, 10, 37
     cp = make_conv(c, c, seed=90)
     dy, saved, skip = rnd(n, c, h, w, seed=91), rnd(n, c, h, w, seed=92), rnd(n, c, h, w, seed=93)
@@ -332,7 +334,8 @@ def test_winograd_backward_epilogue_and_dgrad_packing():
     assert maxerr(nchw(dx), ref) <= TOL
 
 
-def test_winograd_abi_rejects_bad_descriptors():
+def test_winograd_abi_rejects_bad_descriptors(monkeypatch):
+    monkeypatch.setenv("VIRNET_WINOGRAD", "1")
     cp = make_conv(64, 64).cuda()
     pw = cp.packed()
     x = torch.zeros(1, 4, 4, 64, device="cuda")
