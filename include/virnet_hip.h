@@ -123,6 +123,21 @@ int virnet_pack_wino_weight(const float* w_oihw, int dgrad, int cout, int cin, i
 int virnet_conv_wino(const virnet_conv_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same stride-1 3x3 convolution on the f16 matrix pipe with SPLIT fp32 operands (csrc/conv_f16.hip): every fp32 weight and
+ * activation is written exactly as hi + lo in fp16 and w*x is evaluated as w_lo*x_hi + w_hi*x_lo + w_hi*x_hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp32-class results (measured error vs fp64 no larger than the fp32 MFMA
+ * chain's, profiles/r02_probes.md) at 3/16 of the fp32 matrix pipe's cycles.  Call sites as virnet_conv_wino: AttResBlock.conv1/
+ * conv2 (AttResUNet.py:55,58 + residual :59), DnCNN mid_layer (DnCNN.py:25-28,39-40), RB_Layer convs (KNet.py:32,34) and their
+ * input-gradient GEMMs.  Takes the SAME descriptor as virnet_conv_mfma with ks = 3, stride = 1, epi = VIRNET_EPI_NHWC, cout a
+ * multiple of 32 (n_pad = cout; nrep is ignored) and `wpack` from virnet_pack_f16_weight: n_pad inverse row scales (fp32) followed
+ * by the split image [n_pad/32][cin_pad/16][9 taps, column-major][hi|lo][64 lanes][8 x fp16].  Weights are scaled per output
+ * channel by a power of two (exact).  `dgrad` as for virnet_pack_wino_weight.  Activations must stay below 65504 in magnitude.
+ * ---------------------------------------------------------------------------------------------- */
+size_t virnet_f16_weight_floats(int cin_pad, int n_pad);
+int virnet_pack_f16_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
+int virnet_conv_f16(const virnet_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):
  * AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173), DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43),
  * KernelNet.tail conv (KNet.py:49).  Weights: virnet_pack_thin_weight of the OIHW tensor.

@@ -1,0 +1,168 @@
+"""GPU parity of the split-fp16 convolution (csrc/conv_f16.hip, VIRNET_CONV_FORM=f16x3) against the CPU oracle and the fp32 direct
+kernel.  The form is held to the SAME 2e-5 bar as the fp32 kernels: three fp16 products per fp32 product with fp32 accumulation
+measure no worse than the fp32 MFMA chain against fp64 (profiles/r02_probes.md)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+from virnet_amd import _native as nat
+from virnet_amd import ops
+from test_ops_gpu import make_conv, maxerr, nchw, nhwc, rnd
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(autouse=True)
+def _form(monkeypatch):
+    monkeypatch.delenv("VIRNET_WINOGRAD", raising=False)
+    monkeypatch.setenv("VIRNET_CONV_FORM", "f16x3")
+
+
+def unpack_f16(img, rows, ks):
+    """packed tensor -> (inverse scales [rows], hi + lo as float64 [rows][ks][3][3]) following include/virnet_hip.h's layout."""
+    inv = img[:rows].cpu().double()
+    raw = img[rows:].cpu().view(torch.float16).double().view(rows // 32, ks // 16, 9, 2, 64, 8)   # [slab][chunk][dx*3+dy][hi|lo][lane][e]
+    val = raw[:, :, :, 0] + raw[:, :, :, 1]                                                     # [slab][chunk][tap][lane][e]
+    val = val.view(rows // 32, ks // 16, 3, 3, 2, 32, 8)                                          # [slab][chunk][dx][dy][khalf][col][e]
+    w = val.permute(0, 5, 1, 4, 6, 3, 2).reshape(rows, ks, 3, 3)                                  # row = slab*32+col, k = chunk*16+khalf*8+e, [dy][dx]
+    return inv, w
+
+
+def test_f16_weight_image_is_scaled_split():
+    """virnet_pack_f16_weight: (hi + lo) * inv_scale reproduces the fp32 weight to 2^-21 relative, scales are powers of two, the
+    scaled row maxima sit in [8192, 16384), forward and input-gradient (flipped, transposed) packings."""
+    cout, cin = 64, 32
+    w = rnd(cout, cin, 3, 3, seed=70) * 0.05
+    w[5] *= 1e-3                                      # a small-norm output channel gets its own scale
+    for dgrad in (False, True):
+        ref = w.double().flip(2, 3).transpose(0, 1) if dgrad else w.double()
+        rows, ks = ref.shape[:2]
+        inv, got = unpack_f16(ops.pack_f16_weight(w.cuda(), dgrad=dgrad), rows, ks)
+        assert torch.all(torch.log2(inv) == torch.log2(inv).round())
+        scaled_max = (ref.abs().amax(dim=(1, 2, 3)) / inv)
+        assert torch.all((scaled_max >= 8192) & (scaled_max < 16384))
+        err = ((got * inv.view(-1, 1, 1, 1) - ref).abs() / ref.abs().clamp_min(1e-30)).max()
+        assert float(err) <= 2.0 ** -21, float(err)
+
+
+@pytest.mark.parametrize("mrep", ["1", "2"])
+@pytest.mark.parametrize("c,h,w,n", [(64, 9, 33, 2), (96, 17, 70, 1), (192, 6, 31, 2), (288, 8, 32, 1), (160, 5, 7, 1), (32, 3, 2, 1),
+                                      (96, 40, 64, 4)])
+def test_f16x3_vs_direct_and_oracle(monkeypatch, mrep, c, h, w, n):
+    """Both tile heights against the fp32 direct kernel and the CPU oracle: odd sizes (partial tiles), every slab mix
+    (1, 2, 3 slabs per workgroup; 5 = 160 channels as single slabs), pre-activation, residual + dual store."""
+    monkeypatch.setenv("VIRNET_F16_MREP", mrep)
+    cp = make_conv(c, c, seed=80)
+    x, res = rnd(n, c, h, w, seed=81), rnd(n, c, h, w, seed=82)
+    raw_ref, act_ref = cpu_ref.conv_fused(F.leaky_relu(x, 0.2), cp.weight.detach(), cp.bias.detach(), residual=res, slope=0.25)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.f16 is not None
+    kw = dict(in_slope=0.2, res=nhwc(res), want_raw=True, want_act=True, slope=0.25)
+    raw_h, act_h = ops.conv_mfma(nhwc(x), pw, **kw)
+    monkeypatch.setenv("VIRNET_CONV_FORM", "direct")
+    raw_d, _ = ops.conv_mfma(nhwc(x), pw, **kw)
+    assert maxerr(nchw(raw_h), raw_ref) <= TOL and maxerr(nchw(act_h), act_ref) <= TOL
+    assert maxerr(raw_h.cpu(), raw_d.cpu()) <= TOL
+
+
+def test_f16x3_wide_dynamic_range(monkeypatch):
+    """Activations spanning 1e-6 .. 2e3 and weight rows spanning 1e-4 .. 1: the split keeps fp32-class RELATIVE accuracy
+    (error measured against an fp64 convolution, relative to sum |w||x|)."""
+    c, n, h, w = 96, 1, 12, 40
+    g = np.random.Generator(np.random.Philox(key=[5, 5]))
+    x = torch.from_numpy((g.standard_normal((n, c, h, w)) * np.exp(g.uniform(-14, 7.5, (n, c, h, w)))).astype(np.float32))
+    cp = make_conv(c, c, seed=11)
+    with torch.no_grad():
+        cp.weight.mul_(torch.from_numpy(np.exp(g.uniform(-9, 0, (c, 1, 1, 1))).astype(np.float32)))
+    ref = F.conv2d(x.double(), cp.weight.detach().double(), cp.bias.detach().double(), padding=1)
+    mag = F.conv2d(x.double().abs(), cp.weight.detach().double().abs(), None, padding=1) + cp.bias.detach().double().abs().view(1, -1, 1, 1)
+    cp.cuda()
+    raw, _ = ops.conv_mfma(nhwc(x), cp.packed(), want_raw=True)
+    rel = float(((nchw(raw).double() - ref).abs() / mag).max())
+    monkeypatch.setenv("VIRNET_CONV_FORM", "direct")
+    raw_d, _ = ops.conv_mfma(nhwc(x), cp.packed(), want_raw=True)
+    rel_d = float(((nchw(raw_d).double() - ref).abs() / mag).max())
+    print(f"relative error vs fp64: f16x3 {rel:.2e}, fp32 direct {rel_d:.2e}")
+    # fp32-class: within a few fp32 ulps of sum|w||x| like the fp32 kernel; a plain fp16 path would be ~5e-4, bf16x3 ~1e-5
+    assert rel <= 1e-6 and rel <= 4 * max(rel_d, 1.5e-7), (rel, rel_d)
+
+
+def test_f16x3_backward_epilogue_and_dgrad_packing():
+    """Input gradient of a res-block conv: dgrad packing + LeakyReLU-derivative mask + residual add."""
+    c, n, h, w = 96, 2, 10, 37
+    cp = make_conv(c, c, seed=90)
+    dy, saved, skip = rnd(n, c, h, w, seed=91), rnd(n, c, h, w, seed=92), rnd(n, c, h, w, seed=93)
+    ref = F.conv_transpose2d(dy, cp.weight.detach(), padding=1) * torch.where(saved > 0, 1.0, 0.2) + skip
+    cp.cuda()
+    pw = cp.packed_dgrad()
+    assert pw.f16 is not None
+    dx, _ = ops.conv_mfma(nhwc(dy), pw, mask=nhwc(saved), mask_slope=0.2, res=nhwc(skip), want_raw=True)
+    assert maxerr(nchw(dx), ref) <= TOL
+
+
+def test_f16x3_abi_rejects_bad_descriptors():
+    cp = make_conv(64, 64).cuda()
+    pw = cp.packed()
+    x = torch.zeros(1, 4, 4, 64, device="cuda")
+    y = torch.empty(1, 4, 4, 64, device="cuda")
+
+    def desc(**over):
+        d = dict(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=0, res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0, y_raw=nat.ptr(y),
+                 y_act=0, n=1, h=4, w=4, cin_pad=64, cout=64, n_pad=64, nrep=1, ks=3, stride=1, epi=nat.EPI_NHWC, nchw_op=0, crop_h=0, crop_w=0,
+                 res_sf=1, in_act=0, in_slope=0.0, slope=0.0, clamp_lo=0.0, clamp_hi=0.0)
+        d.update(over)
+        return nat.ConvDesc(**d)
+    lib = nat.load()
+    assert lib.virnet_conv_f16(C.byref(desc()), nat.stream_handle()) == 0
+    for bad in (dict(stride=2), dict(ks=1), dict(cout=48, n_pad=48), dict(epi=nat.EPI_NCHW), dict(y_raw=0), dict(cin_pad=24), dict(in_mul=nat.ptr(x))):
+        assert lib.virnet_conv_f16(C.byref(desc(**bad)), nat.stream_handle()) != 0, bad
+        assert lib.virnet_last_error()
+    torch.cuda.synchronize()
+
+
+def test_f16x3_randomised_sweep_against_direct_kernel(monkeypatch):
+    """Seeded sweep over shapes / channel mixes / epilogue options: the split-fp16 kernel (both tile heights) must agree with the
+    fp32 direct kernel run on the same tensors -- catches ordering bugs (buffer reuse, partial tiles, odd chunk counts)."""
+    g = np.random.Generator(np.random.Philox(key=[78, 3]))
+    chans = [32, 48, 64, 96, 128, 160, 192, 224, 288]
+    worst = 0.0
+    for case in range(40):
+        cin, cout = int(g.choice(chans)), int(g.choice([c for c in chans if c % 32 == 0]))
+        n, h, w = int(g.integers(1, 4)), int(g.integers(1, 41)), int(g.integers(1, 75))
+        opts = dict(pre=bool(g.integers(0, 2)), res=bool(g.integers(0, 2)), mask=bool(g.integers(0, 2)), sft=bool(g.integers(0, 3) == 0),
+                    dual=bool(g.integers(0, 2)))
+        cp = make_conv(cin, cout, seed=200 + case).cuda()
+        cpad = (cin + 15) // 16 * 16
+        xc = rnd(n, cin, h, w, seed=300 + case)
+        x = nhwc(F.pad(xc, (0, 0, 0, 0, 0, cpad - cin)))
+        kw = dict(want_raw=True, want_act=opts["dual"], slope=0.2)
+        if opts["pre"] or opts["sft"]:
+            kw["in_slope"] = 0.2
+        if opts["sft"]:
+            kw.update(in_mul=rnd(n, cpad, seed=400 + case, lo=0.3, hi=1.0).cuda(), in_add=rnd(n, cpad, seed=500 + case).cuda(),
+                      mul=rnd(n, cout, seed=600 + case, lo=0.3, hi=1.0).cuda(), add=rnd(n, cout, seed=700 + case).cuda())
+        if opts["res"]:
+            kw["res"] = nhwc(rnd(n, cout, h, w, seed=800 + case))
+        if opts["mask"]:
+            kw.update(mask=nhwc(rnd(n, cout, h, w, seed=900 + case)), mask_slope=0.25)
+        monkeypatch.setenv("VIRNET_CONV_FORM", "f16x3")
+        pw = cp.packed()
+        assert pw.f16 is not None
+        outs = {}
+        for form in ("1", "2", "direct"):
+            monkeypatch.setenv("VIRNET_CONV_FORM", "direct" if form == "direct" else "f16x3")
+            monkeypatch.setenv("VIRNET_F16_MREP", form if form != "direct" else "1")
+            outs[form] = ops.conv_mfma(x, pw, **kw)
+        for form in ("1", "2"):
+            for a, b in zip(outs[form], outs["direct"]):
+                if a is not None:
+                    e = maxerr(a.cpu(), b.cpu())
+                    worst = max(worst, e)
+                    assert e <= 5e-5, (case, form, cin, cout, n, h, w, opts, e)
+    assert worst > 0.0

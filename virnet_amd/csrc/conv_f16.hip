@@ -1,0 +1,451 @@
+// conv_f16.hip -- the 3x3 convolution as an implicit GEMM on the CDNA4 f16 matrix pipe with SPLIT fp32 operands (gfx950).
+//
+// Same call sites as conv_mfma.hip / wino.hip (AttResBlock.conv1/conv2, networks/AttResUNet.py:43,46,55,58; DnCNN mid convs,
+// networks/DnCNN.py:25-28; RB_Layer convs, networks/KNet.py:32,34) and their input-gradient GEMMs.
+//
+// Arithmetic.  Every fp32 operand is split exactly into two fp16 numbers, v = hi + lo (hi = rne16(v), lo = rne16(v - hi); the
+// residual is <= 2^-23 |v|, or <= 2^-25 absolute once lo is subnormal -- gfx950's MFMA keeps fp16 subnormals, measured), and
+//     w * x  ~=  w_lo * x_hi + w_hi * x_lo + w_hi * x_hi
+// runs as three v_mfma_f32_32x32x16_f16 (fp16 products are exact in fp32; accumulation is fp32).  The dropped term w_lo * x_lo is
+// <= 2^-22 |w x|.  Weights are pre-scaled per output channel by a power of two (exact) so their low halves stay normal; the
+// epilogue multiplies by the inverse.  Measured on MI355X against fp64 (profiles/r02_probes.md): K = 864 dot products 6.8e-8 of
+// sum|w x| (the fp32 MFMA chain: 1.3e-7); whole denoise-syn network 8.0e-6 max-abs on mu (fp32: 8.9e-6).  The f16 pipe retires
+// 16x the MACs of the fp32 pipe per cycle, so three products cost 3/16 of the fp32 direct form (Winograd F(2x2,3x3): 7.1/16).
+// Range: activations must stay below 65504 in magnitude (fp16 max); beyond it the result is Inf/NaN, never silently wrong.
+//
+// GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (tap, cin).  Workgroup = 4 waves = (4*MREP) output rows x 32 output
+// columns x 32*NREP output channels; wave w owns rows [w*MREP, (w+1)*MREP) x all channels (MREP x NREP accumulator blocks of 32x32).
+// K is walked as 16-channel chunks x 9 taps; one (tap, chunk) is ONE MFMA k-step, three products deep.
+//   X (pixels): per chunk a halo tile in LDS as two planes (hi, lo) of 32-B pixel records (16 fp16 channels), 16-B slot s of pixel p
+//               stored at s ^ ((p>>3)&1): ds_read_b128 B-fragments are bank-conflict free for every tap shift.  Pixels are fetched
+//               global -> registers (fp32), pre-activated (AttResUNet.py:54-55: lrelu(x*mul+add), zero outside the image AFTER it),
+//               split and written to the other buffer one third per tap group.
+//   W (weights): pre-split, pre-scaled, packed as the exact LDS image [tap][slab][hi|lo][lane][16 B]; streamed global -> LDS by
+//               DMA (global_load_lds_dwordx4), three taps (one kernel column) per stage, double buffered.
+//   Taps run column by column (dx outer): the MREP+2 input rows a wave needs for one dx are read ONCE and serve all three dy.
+// One barrier per tap group (54 MFMAs per wave at 2x3 blocks); two workgroups per CU cover each other's barriers and epilogues.
+// Epilogue: as conv_mfma.hip (lane = pixel, accumulator quad = 4 consecutive channels, 16-B accesses) after the inverse scale.
+#include "common.h"
+#include "../../include/virnet_hip.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+struct FArgs {
+  const float* x;
+  const char* wimg;        // [slab][chunk][tap'][hi|lo][lane][16 B]
+  const float* inv_scale;  // [NP]
+  const float* bias;
+  const float* res;
+  const float* mul;
+  const float* add;
+  const float* in_mul;
+  const float* in_add;
+  const float* mask;
+  float* y_raw;
+  float* y_act;
+  int N, H, W, Cin;
+  int NP, cout;
+  int ntx, nty, ntiles, tiles_per_xcd;
+  int in_act;
+  float in_slope, mask_slope, slope;
+};
+
+__device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
+  const f32x4 t = u * s;
+  return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
+}
+
+// v = hi + lo in fp16 (round to nearest even both times)
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+
+template <int MREP, int NREP>
+__global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
+  constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
+  constexpr int NPIECE = NPIX * 2;                 // (pixel, 8-channel half) staging pieces of one chunk
+  constexpr int PPT = (NPIECE + 255) / 256;
+  static_assert(PPT <= 3, "one staged piece per tap group");
+  constexpr int PLANE = NPIX * 32, XB = 2 * PLANE;
+  constexpr int WGRP = 3 * NREP * 2048;            // one tap group (three taps) of weight fragments
+  constexpr int NDMA = 3 * NREP * 2;               // ... in 1-KB DMA pieces
+  constexpr int NR = MREP + 2;                     // input rows per wave and kernel column
+  constexpr int NB = 32 * NREP;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const x_lds = smem;                        // [2][hi plane | lo plane]
+  char* const w_lds = smem + 2 * XB;               // [2][3 taps][NREP][hi|lo][1 KB]
+
+  // ---- workgroup -> (tile, channel block): contiguous tile ranges per XCD (block b runs on XCD b%8), channel blocks adjacent
+  const int ncb = a.NP / NB;
+  const int xcd = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int cb = __builtin_amdgcn_readfirstlane(q % ncb);
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + q / ncb);
+  if (q / ncb >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx = __builtin_amdgcn_readfirstlane(tile % a.ntx);
+  const int ty = __builtin_amdgcn_readfirstlane((tile / a.ntx) % a.nty);
+  const int img = __builtin_amdgcn_readfirstlane(tile / (a.ntx * a.nty));
+  const int oy0 = ty * TH, ox0 = tx * 32;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int nch = a.Cin >> 4;
+  const int nstages = nch * 3;
+  const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
+
+  // ---- pixel staging: piece k of this thread = (pixel p, half h = tid&1) -> 8 channels chunk*16 + 8h .. of pixel p
+  unsigned soff[PPT];
+  int sdst[PPT];
+  bool sinb[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int qq = k * 256 + tid;
+    const bool has = qq < NPIECE;
+    const int qc = has ? qq : 0;
+    const int p = qc >> 1, h = qc & 1;
+    const int iy = p / IW, ix = p - iy * IW;
+    const int gy = iy0 + iy, gx = ix0 + ix;
+    sinb[k] = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+    soff[k] = (unsigned)((gyc * a.W + gxc) * a.Cin + h * 8);
+    sdst[k] = has ? p * 32 + ((h ^ ((p >> 3) & 1)) << 4) : -1;
+  }
+  const bool in_sft = a.in_mul != nullptr;
+  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + (tid & 1) * 8 : nullptr;
+  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + (tid & 1) * 8 : nullptr;
+  const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  auto stage_store = [&](char* xb, int chunk, int k, f32x4 r0, f32x4 r1) {
+    if (in_sft) {
+      const f32x4 m0 = *reinterpret_cast<const f32x4*>(imul + chunk * 16), m1 = *reinterpret_cast<const f32x4*>(imul + chunk * 16 + 4);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(iadd + chunk * 16), a1 = *reinterpret_cast<const f32x4*>(iadd + chunk * 16 + 4);
+      r0 = r0 * m0 + a0;
+      r1 = r1 * m1 + a1;
+    }
+    r0 = lrelu4(r0, in_slope_eff);
+    r1 = lrelu4(r1, in_slope_eff);
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    r0 = sinb[k] ? r0 : z;
+    r1 = sinb[k] ? r1 : z;
+    h8 hi, lo;
+    split8(r0, r1, hi, lo);
+    if (sdst[k] >= 0) {
+      *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
+      *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
+    }
+  };
+
+  // ---- weight DMA: piece q = (tap-in-group, slab, hi|lo), 1 KB = the fragment of one MFMA operand; wave w moves pieces w, w+4, ...
+  const size_t slab_bytes = (size_t)nch * 9 * 2048;
+  const char* const wcb = a.wimg + (size_t)(cb * NREP) * slab_bytes + lane * 16;
+  auto dma_group = [&](int stage, char* wb) {
+#pragma unroll
+    for (int i = 0; i < (NDMA + 3) / 4; ++i) {
+      const int qd = i * 4 + wave;
+      if (qd < NDMA) {
+        const int tg = qd / (NREP * 2), rem = qd - tg * (NREP * 2);
+        const char* src = wcb + (size_t)(rem >> 1) * slab_bytes + (size_t)((stage * 3 + tg) * 2 + (rem & 1)) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wb + qd * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addressing
+  // B (pixels): row r of this wave (input row wave*MREP + r), kernel column dx: pixel p = (wave*MREP + r)*IW + l31 + dx
+  int boff[NR][3];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int p = (wave * MREP + r) * IW + l31 + dx;
+      boff[r][dx] = p * 32 + ((lhi ^ ((p >> 3) & 1)) << 4);
+    }
+  const int aoff = lane * 16;
+
+  f32x16 acc[MREP][NREP];
+#pragma unroll
+  for (int mr = 0; mr < MREP; ++mr)
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
+
+  // ---- prologue: weights of stage 0 by DMA, pixels of chunk 0 staged whole, chunk 1's first pieces requested by group 0
+  dma_group(0, w_lds);
+  {
+    f32x4 r0[PPT], r1[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      r0[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k]);
+      r1[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k] + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) stage_store(x_lds, 0, k, r0[k], r1[k]);
+  }
+  __syncthreads();
+
+  h8 ah[2][NREP], al[2][NREP];      // A fragments (weights) of tap t and t+1
+  h8 bh[NR], bl[NR];                // B fragments (pixels) of the current kernel column
+  auto read_a = [&](const char* wb, int tg, h8 (&h)[NREP], h8 (&l)[NREP]) {
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      h[nr] = *reinterpret_cast<const h8*>(wb + ((tg * NREP + nr) * 2 + 0) * 1024 + aoff);
+      l[nr] = *reinterpret_cast<const h8*>(wb + ((tg * NREP + nr) * 2 + 1) * 1024 + aoff);
+    }
+  };
+  auto read_b = [&](const char* xb, int r, int dx) {
+    bh[r] = *reinterpret_cast<const h8*>(xb + boff[r][dx]);
+    bl[r] = *reinterpret_cast<const h8*>(xb + PLANE + boff[r][dx]);
+  };
+
+  // One tap group = kernel column g of chunk c (P = c&1: pixel buffer; weight buffer (P+g)&1; A register set (P + 3g + dy)&1).
+  auto group = [&](int c, auto pc, auto gc) {
+    constexpr int P = decltype(pc)::value, g = decltype(gc)::value;
+    const int stage = c * 3 + g;
+    const char* const xb = x_lds + P * XB;
+    char* const xn = x_lds + (P ^ 1) * XB;
+    const char* const wb = w_lds + ((P + g) & 1) * WGRP;
+    char* const wn = w_lds + ((P + g + 1) & 1) * WGRP;
+    const bool more_w = stage + 1 < nstages, more_x = c + 1 < nch;
+    if (more_w) dma_group(stage + 1, wn);
+    f32x4 s0, s1;
+    if (g < PPT) {
+      const float* const src = ximg + soff[g] + (more_x ? (c + 1) * 16 : c * 16);
+      s0 = *reinterpret_cast<const f32x4*>(src);
+      s1 = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+    // operands of this group's first tap (the weights only became visible at the barrier)
+    read_a(wb, 0, ah[(P + 3 * g) & 1], al[(P + 3 * g) & 1]);
+    if (g == 0) {
+#pragma unroll
+      for (int r = 0; r < MREP; ++r) read_b(xb, r, 0);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      constexpr int dummy = 0; (void)dummy;
+      const int cur = (P + 3 * g + dy) & 1;
+      SB();
+      // requests for the next tap: its weights (same group) and the input row it needs first; at the last tap of a column the
+      // first rows of the next column (same chunk) -- those registers were last used by tap dy = 1
+      if (dy < 2) {
+        read_a(wb, dy + 1, ah[cur ^ 1], al[cur ^ 1]);
+        read_b(xb, MREP + dy, g);
+      } else if (g < 2) {
+#pragma unroll
+        for (int r = 0; r < MREP; ++r) read_b(xb, r, g + 1);
+      }
+      SB();
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int mr = 0; mr < MREP; ++mr)
+#pragma unroll
+          for (int nr = 0; nr < NREP; ++nr) {
+            const h8 wa = (part == 0) ? al[cur][nr] : ah[cur][nr];
+            const h8 xv = (part == 1) ? bl[mr + dy] : bh[mr + dy];
+            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[mr][nr], 0, 0, 0);
+          }
+    }
+    SB();
+    if (g < PPT && more_x) stage_store(xn, c + 1, g, s0, s1);
+    __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int c = 0;
+  for (; c + 1 < nch; c += 2) {
+    group(c, I0{}, I0{}); group(c, I0{}, I1{}); group(c, I0{}, I2{});
+    group(c + 1, I1{}, I0{}); group(c + 1, I1{}, I1{}); group(c + 1, I1{}, I2{});
+  }
+  if (c < nch) { group(c, I0{}, I0{}); group(c, I0{}, I1{}); group(c, I0{}, I2{}); }
+
+  // ---- epilogue: lane = pixel (ox0 + l31), accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3)
+  const int nbase = cb * NB;
+  const int px = ox0 + l31;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int C = a.cout;
+  const size_t img_off = (size_t)img * a.H * a.W * C;
+  const float* const rimg = a.res ? a.res + img_off : nullptr;
+  const float* const mimg = a.mask ? a.mask + img_off : nullptr;
+  float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+  float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
+  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
+  unsigned eo[MREP];
+  bool ok[MREP];
+#pragma unroll
+  for (int mr = 0; mr < MREP; ++mr) {
+    const int oy = oy0 + wave * MREP + mr;
+    ok[mr] = oy < a.H && px < a.W;
+    eo[mr] = (unsigned)(min(oy, a.H - 1) * a.W + min(px, a.W - 1)) * (unsigned)C;
+  }
+#pragma unroll
+  for (int nr = 0; nr < NREP; ++nr) {
+    f32x4 bias[4], inv[4], rv[4][MREP], mv[4][MREP];
+    unsigned off[4][MREP];
+    int cog[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = nbase + nr * 32 + 8 * g + 4 * lhi;
+      cog[g] = co;
+      bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
+      inv[g] = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
+#pragma unroll
+      for (int mr = 0; mr < MREP; ++mr) {
+        off[g][mr] = eo[mr] + (unsigned)co;
+        rv[g][mr] = rimg ? *reinterpret_cast<const f32x4*>(rimg + off[g][mr]) : zero4;
+        if (mimg) mv[g][mr] = *reinterpret_cast<const f32x4*>(mimg + off[g][mr]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
+      if (mulp) {
+        mul = *reinterpret_cast<const f32x4*>(mulp + cog[g]);
+        add = *reinterpret_cast<const f32x4*>(addp + cog[g]);
+      }
+#pragma unroll
+      for (int mr = 0; mr < MREP; ++mr) {
+        f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} * inv[g] + bias[g];
+        if (mimg) {
+          const f32x4 m = mv[g][mr];
+          v = f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
+                    m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+        }
+        v += rv[g][mr];
+        if (ok[mr]) {
+          if (yraw) *reinterpret_cast<f32x4*>(yraw + off[g][mr]) = v;
+          if (yact) *reinterpret_cast<f32x4*>(yact + off[g][mr]) = lrelu4(v * mul + add, a.slope);
+        }
+      }
+    }
+  }
+}
+
+template <int MREP, int NREP>
+int launch(FArgs k, hipStream_t st) {
+  constexpr int TH = 4 * MREP;
+  constexpr int LDS = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);
+  static unsigned long long attr_done = 0;
+  auto kern = conv_f16_kernel<MREP, NREP>;
+  if (virnet::first_use_on_device(attr_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16): %s", hipGetErrorString(e));
+  }
+  k.nty = (k.H + TH - 1) / TH;
+  k.ntx = (k.W + 31) / 32;
+  k.ntiles = k.N * k.nty * k.ntx;
+  k.tiles_per_xcd = (k.ntiles + 7) / 8;
+  const int ncb = k.NP / (32 * NREP);
+  const unsigned grid = (unsigned)(8 * k.tiles_per_xcd * ncb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, k);
+  return virnet::check_launch("conv_f16 launch");
+}
+
+// ---- weight packing -------------------------------------------------------------------------------------------------------
+// One block per GEMM row (output channel): power-of-two scale from the row's largest magnitude, then the split image.
+// kind 0: forward OIHW; kind 2: the layer's input-gradient GEMM (rows = forward cin, contraction = forward cout, flipped taps).
+__global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout, int cin, int cin_pad, int n_pad,
+                                float* __restrict__ inv_scale, char* __restrict__ img) {
+  const int row = blockIdx.x;
+  const int rows = kind == 2 ? cin : cout, ks = kind == 2 ? cout : cin;
+  const int nch = cin_pad >> 4;
+  auto wval = [&](int k, int dy, int dx) -> float {
+    if (row >= rows || k >= ks) return 0.f;
+    return kind == 2 ? w[(((size_t)k * cin + row) * 3 + (2 - dy)) * 3 + (2 - dx)] : w[(((size_t)row * cin + k) * 3 + dy) * 3 + dx];
+  };
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < ks * 9; i += blockDim.x) m = fmaxf(m, fabsf(wval(i / 9, (i % 9) / 3, i % 3)));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  // largest scaled magnitude in [8192, 16384): two bits of headroom below fp16's 65504, low halves normal down to 2^-17 of it
+  int e = 0;
+  if (m > 0.f) { frexpf(m, &e); e = 14 - e; }
+  e = max(-100, min(100, e));
+  const float scale = ldexpf(1.f, e);
+  if (threadIdx.x == 0) inv_scale[row] = ldexpf(1.f, -e);
+  const int slab = row >> 5, col = row & 31;
+  for (int i = threadIdx.x; i < cin_pad * 9; i += blockDim.x) {
+    const int k = i / 9, t = i % 9, dy = t / 3, dx = t % 3;
+    const float v = wval(k, dy, dx) * scale;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const int chunk = k >> 4, kk = k & 15;
+    const size_t base = ((((size_t)slab * nch + chunk) * 9 + (dx * 3 + dy)) * 2) * 1024 + (size_t)(col + 32 * (kk >> 3)) * 16 + (kk & 7) * 2;
+    *reinterpret_cast<_Float16*>(img + base) = hi;
+    *reinterpret_cast<_Float16*>(img + base + 1024) = lo;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t virnet_f16_weight_floats(int cin_pad, int n_pad) { return (size_t)n_pad + (size_t)n_pad * cin_pad * 9; }
+
+extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream) {
+  VIRNET_REQUIRE(w && packed, "virnet_pack_f16_weight: NULL pointer");
+  VIRNET_REQUIRE(cout > 0 && cin > 0, "virnet_pack_f16_weight: bad extents cout=%d cin=%d", cout, cin);
+  const int rows = dgrad ? cin : cout, ks = dgrad ? cout : cin;
+  VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= ks, "virnet_pack_f16_weight: cin_pad=%d does not cover %d contraction channels", cin_pad, ks);
+  VIRNET_REQUIRE(n_pad % 32 == 0 && n_pad >= rows, "virnet_pack_f16_weight: n_pad=%d does not cover %d output channels", n_pad, rows);
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)n_pad), dim3(256), 0, static_cast<hipStream_t>(stream), w, dgrad ? 2 : 0, cout, cin,
+                     cin_pad, n_pad, packed, reinterpret_cast<char*>(packed + n_pad));
+  return virnet::check_launch("pack_f16 launch");
+}
+
+extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
+  VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
+  VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_f16: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
+                 d->ks, d->stride, d->epi);
+  VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_f16: empty input n=%d h=%d w=%d", d->n, d->h, d->w);
+  VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_f16: cin_pad=%d is not a multiple of 16", d->cin_pad);
+  VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_f16: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
+  VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_f16: no output pointer");
+  VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_f16: in_mul and in_add must be given together");
+  VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_f16: in_mul/in_add without in_act");
+  VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_f16: in_slope=%g outside [0,1]", d->in_slope);
+  VIRNET_REQUIRE(!d->y_act || (d->slope >= 0.f && d->slope <= 1.f), "virnet_conv_f16: slope=%g outside [0,1]", d->slope);
+  FArgs k{};
+  k.x = d->x; k.inv_scale = d->wpack; k.wimg = reinterpret_cast<const char*>(d->wpack + d->n_pad);
+  k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
+  k.in_mul = d->in_mul; k.in_add = d->in_add; k.mask = d->mask; k.y_raw = d->y_raw; k.y_act = d->y_act;
+  k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.NP = d->n_pad; k.cout = d->cout;
+  k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nb = d->cout / 32;
+  const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
+  const char* const env_m = getenv("VIRNET_F16_MREP");      // tuning / tests (read per call)
+  const int forced_m = env_m ? atoi(env_m) : 0;
+  const int nrep = (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
+  int mrep = (tiles8 * (nb / nrep) >= 1024) ? 2 : 1;
+  if (forced_m == 1 || forced_m == 2) mrep = forced_m;
+#define VIRNET_F16_CASE(M_, N_) if (mrep == M_ && nrep == N_) return launch<M_, N_>(k, st)
+  VIRNET_F16_CASE(2, 3); VIRNET_F16_CASE(2, 2); VIRNET_F16_CASE(2, 1);
+  VIRNET_F16_CASE(1, 3); VIRNET_F16_CASE(1, 2); VIRNET_F16_CASE(1, 1);
+#undef VIRNET_F16_CASE
+  return virnet::set_error("virnet_conv_f16: no kernel for mrep=%d nrep=%d", mrep, nrep);
+}

@@ -39,7 +39,7 @@ class ConvParam(nn.Module):
     def packed(self) -> ops.PackedWeight:
         """Packed weight for the MFMA kernel, rebuilt when the parameter storage or version changed."""
         key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),
-               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version), ops.conv_form())
         if self._pack is None or self._pack_key != key:
             self._pack = ops.pack_weight(self.weight, self.bias, transposed=self.transposed, stride=self.stride)
             self._pack_key = key
@@ -47,7 +47,7 @@ class ConvParam(nn.Module):
 
     def packed_dgrad(self) -> ops.PackedWeight:
         """Packing of this layer's input-gradient GEMM (training step), cached like ``packed``."""
-        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device))
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device), ops.conv_form())
         if getattr(self, "_dgrad", None) is None or self._dgrad_key != key:
             self._dgrad = ops.pack_weight(self.weight, None, transposed=self.transposed, dgrad=True)
             self._dgrad_key = key

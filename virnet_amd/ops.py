@@ -29,6 +29,7 @@ class PackedWeight:
     nrep: int
     transposed: bool
     wino: Optional[Tensor] = None   # Winograd-domain image (virnet_pack_wino_weight) of a stride-1 3x3 layer, when eligible
+    f16: Optional[Tensor] = None    # split-fp16 image (virnet_pack_f16_weight) of a stride-1 3x3 layer, when eligible
 
 
 class LaunchTimer:
@@ -58,14 +59,14 @@ def set_launch_timer(t: Optional[LaunchTimer]) -> None:
     _TIMER = t
 
 
-def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, wino: bool = False) -> None:
+def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct") -> None:
     lib = nat.load()
-    fn = lib.virnet_conv_wino if wino else lib.virnet_conv_mfma
+    fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "direct": lib.virnet_conv_mfma}[form]
     if _TIMER is None:
         nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
-    if wino:
-        key = ("wino", d.cout)
+    if form != "direct":
+        key = (form, d.cout)
     else:
         var = (C.c_int * 4)()
         nat.check(lib.virnet_conv_mfma_variant(C.byref(d), C.byref(var)), what)
@@ -77,14 +78,46 @@ def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, wino: bool = False)
     _TIMER.records.append((key, flops, e0, e1))
 
 
-# The Winograd form serves every stride-1 3x3 layer whose channel counts fill MFMA blocks; VIRNET_WINOGRAD=0 keeps the direct form
-# (tuning / A-B runs).
+# Three forms of the stride-1 3x3 convolution whose channel counts fill MFMA blocks (read per call: tests flip it):
+#   VIRNET_CONV_FORM=f16x3   split-fp16 operands on the f16 matrix pipe (csrc/conv_f16.hip) -- the default
+#   VIRNET_CONV_FORM=wino    Winograd F(2x2,3x3) on the fp32 matrix pipe (csrc/wino_row.hip)
+#   VIRNET_CONV_FORM=direct  fp32 implicit GEMM (csrc/conv_mfma.hip)
+# (older spelling, honoured when VIRNET_CONV_FORM is unset: VIRNET_WINOGRAD=0 -> direct, VIRNET_WINOGRAD=1 -> wino)
 WINO_MIN_CHANNELS = 32
+DEFAULT_CONV_FORM = "f16x3"
+
+
+def conv_form() -> str:
+    import os
+    form = os.environ.get("VIRNET_CONV_FORM")
+    if form is None:
+        legacy = os.environ.get("VIRNET_WINOGRAD")
+        form = DEFAULT_CONV_FORM if legacy is None else ("direct" if legacy == "0" else "wino")
+    if form not in ("f16x3", "wino", "direct"):
+        raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected f16x3, wino or direct")
+    return form
 
 
 def _wino_enabled() -> bool:
-    import os
-    return os.environ.get("VIRNET_WINOGRAD", "1") != "0"
+    return conv_form() == "wino"
+
+
+def pack_f16_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
+    """Split-fp16 image (+ per-row inverse scales) of an OIHW 3x3 weight for virnet_conv_f16 (``dgrad``: of the input-gradient GEMM)."""
+    lib = nat.load()
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("the split-fp16 form is for 3x3 kernels")
+    rows, ks = (cin, cout) if dgrad else (cout, cin)
+    if rows % 32:
+        raise ValueError(f"the split-fp16 kernel stores multiples of 32 channels, got {rows}")
+    cin_pad = (ks + 15) // 16 * 16
+    out = torch.empty(lib.virnet_f16_weight_floats(cin_pad, rows), dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_f16_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, rows, nat.ptr(out), nat.stream_handle()),
+              "pack_f16_weight")
+    return out
 
 
 def pack_wino_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
@@ -146,8 +179,11 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         nat.check(lib.virnet_pack_weight(nat.ptr(weight), kind, cout, cin, ks, plan.cin_pad, plan.n_pad, plan.nrep, nat.ptr(out),
                                          nat.stream_handle()), "pack_weight(dgrad)")
         pw = PackedWeight(out, None, gemm_ks, cin, (4 * cout if transposed else cout), plan.cin_pad, plan.n_pad, plan.nrep, False)
-        if not transposed and _wino_enabled() and cin % 32 == 0 and cout >= WINO_MIN_CHANNELS:
-            pw.wino = pack_wino_weight(weight, dgrad=True)
+        if not transposed and cin % 32 == 0 and cout >= WINO_MIN_CHANNELS:
+            if conv_form() == "wino":
+                pw.wino = pack_wino_weight(weight, dgrad=True)
+            elif conv_form() == "f16x3":
+                pw.f16 = pack_f16_weight(weight, dgrad=True)
         return pw
     if transposed:
         cin, cout, kh, kw = weight.shape
@@ -170,8 +206,11 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         b = bias.detach()
         _dev_check(b, "bias")
     pw = PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
-    if kind == 0 and ks == 3 and stride == 1 and _wino_enabled() and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
-        pw.wino = pack_wino_weight(weight)
+    if kind == 0 and ks == 3 and stride == 1 and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
+        if conv_form() == "wino":
+            pw.wino = pack_wino_weight(weight)
+        elif conv_form() == "f16x3":
+            pw.f16 = pack_f16_weight(weight)
     return pw
 
 
@@ -206,15 +245,22 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         raise ValueError(f"in_mul/in_add must be [{n}, {c}]")
     if res is not None and tuple(res.shape) != (n, oh, ow, cstore):
         raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, cstore)}")
-    wino = pw.wino is not None and stride == 1 and epi == nat.EPI_NHWC and cstore == pw.cout and _wino_enabled()
-    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.wino if wino else pw.w), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
+    form = "direct"
+    if stride == 1 and epi == nat.EPI_NHWC and cstore == pw.cout:
+        want = conv_form()
+        if want == "wino" and pw.wino is not None:
+            form = "wino"
+        elif want == "f16x3" and pw.f16 is not None:
+            form = "f16x3"
+    wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16}[form]
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
                      stride=stride, epi=epi, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=int(in_slope is not None),
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
-    _launch_conv(d, flops, "conv_wino" if wino else "conv_mfma", wino)
+    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16"}[form], form)
     return raw, act
 
 
