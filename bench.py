@@ -9,10 +9,16 @@ BASELINE.json's metric is quoted on -- 256x256x3 images, 32 per GPU (configs[2]'
 configs[2]'s 256).  ``--size 128 --batch 64`` runs configs[1].  Scaling is weak: every rank owns ``--batch`` images, the only
 collective is the start-up weight broadcast (RCCL), nothing is exchanged per image.
 
+``--gpus N`` without a torchrun environment re-executes itself through ``torch.distributed.run`` (N ranks on this node), so the
+plain command works as well as the torchrun one.
+
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  roofline     : the dominant kernel (the launch group of the C->C 3x3 res-block convs: conv_wino_row_kernel, or conv_mfma_kernel<3,1,2,3> with VIRNET_WINOGRAD=0) -- algorithmic FLOPs per launch / its
-                 average launch duration, measured with HIP events recorded on the launch stream around every launch inside the
-                 timed region (rank 0), against the 157.3 TFLOP/s fp32-MFMA peak
+  roofline     : the dominant kernel = the launch group of the C->C 3x3 res-block convs with the most time (conv_f16_kernel by
+                 default; conv_wino_row_kernel / conv_mfma_kernel with VIRNET_CONV_FORM=wino|direct).  Launch durations are
+                 measured with HIP events recorded on the launch stream around every launch inside the timed region (rank 0).
+                 `achieved` = FLOPs the kernel EXECUTES on its matrix pipe per second (algorithmic 2*MAC x the form's factor:
+                 f16x3 3 products per MAC, Winograd 16/36, direct 1), `peak` = that pipe's dense peak (f16 2500, fp32 157.3
+                 TFLOP/s), so `frac` <= 1 is the pipe's utilisation; `algorithmic_tflops` is the contract's 2*MAC rate.
   cpu_baseline : the CPU oracle (oracle/cpu_ref.py, kind "port") timed on this box's host cores on a bounded sample.
 """
 from __future__ import annotations
@@ -20,6 +26,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,6 +49,11 @@ SISR_CFG = dict(n_feat=[96, 160, 224], dep_S=5, dep_K=8, n_resblocks=2, noise_co
                 noise_avg=True)
 SISR_GFLOP_PER_IMAGE = 180.159         # x4, LR 64x64 -> 256x256 (RNet 178.92, SNet 0.925, KNet 0.311)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0          # same guide: BF16/F16 MFMA ~2.5 PFLOP/s dense (16x the fp32 matrix rate)
+# matrix-pipe FLOPs executed per algorithmic FLOP (2*MAC of the direct 3x3 convolution), and the pipe they run on
+FORMS = {"f16x3": (3.0, F16_MFMA_PEAK_TFLOPS, "split-fp16 operands: 3 products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation"),
+         "wino": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS, "Winograd F(2x2,3x3), fp32: 16/36 of the algorithmic MACs on v_mfma_f32_32x32x2_f32"),
+         "direct": (1.0, FP32_MFMA_PEAK_TFLOPS, "direct implicit GEMM, fp32 on v_mfma_f32_32x32x2_f32")}
 KFLOP_PER_PIXEL = 4988.736             # conv FLOPs (2*MAC) of the denoise-syn forward per padded pixel
 
 
@@ -119,6 +132,15 @@ def main():
         args.size = 128                     # configs/denoising_syn.json:6 patch_size
     batch = args.batch if args.batch is not None else (16 if sisr else 32 if (training or args.size >= 256) else 64)
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU over RCCL, train_denoising_syn.py:280-297's mp.spawn)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank, local_rank, world = vdist.init()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -196,35 +218,35 @@ def main():
                 return "conv3x3_thin<cout=%d>" % k[3]
             if k[0] == "wgrad":
                 return "conv_wgrad<ks=%d,s=%d,t=%d>" % k[1:]
-            if k[0] == "wino":
-                return "conv_wino<cout=%d>" % k[1]
+            if k[0] in ("wino", "f16x3"):
+                return "conv_%s<cout=%d>" % ("f16" if k[0] == "f16x3" else "wino", k[1])
             return "conv_mfma<%d,%d,%d,%d>" % k
-        # dominant kernel = the launch group of the stride-1 3x3 res-block convs with the most time (Winograd form when enabled)
-        cands = ([k for k in summ if k[0] == "wino"] or [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3]
+        # dominant kernel = the launch group of the stride-1 3x3 res-block convs with the most time
+        cands = ([k for k in summ if k[0] in ("wino", "f16x3")] or [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3]
                  or [k for k in summ if k[0] == 3 and k[1] == 1])
         dom = max(cands, key=lambda k: summ[k]["ms"]) if cands else None
         d = summ.get(dom)
         if d:
+            form = dom[0] if dom[0] in FORMS else "direct"
+            factor, peak, how = FORMS[form]
             avg_ms = d["ms"] / d["launches"]
-            achieved = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            algorithmic = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in summ.values())
             pmc = load_pmc_traffic() if (not sisr and not training and args.size == 256 and batch == 32) else None   # measured on this workload only
-            wino = dom[0] == "wino"
-            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                    "traffic": (pmc or {}).get("hbm_bytes_per_launch") if (pmc or {}).get("kernel", "").startswith("conv_wino") == wino else None,
-                    "kernel": ("conv_wino_row_kernel<G,false,%d> (3x3 stride-1, %d channels; G = 1: 4-wave, 2: 8-wave workgroups)" % (dom[1] // 64 * 2 + dom[1] % 64 // 32, dom[1])) if wino else "conv_mfma_kernel<%d,%d,%d,%d>" % dom,
+            kern = {"f16x3": "conv_f16_kernel<MREP,NREP> (3x3 stride-1, %d channels)" % dom[1],
+                    "wino": "conv_wino_row_kernel<G,false,WPU> (3x3 stride-1, %d channels)" % dom[1]}.get(form) or "conv_mfma_kernel<%d,%d,%d,%d>" % dom
+            roof = {"bound": "mfma", "achieved": round(algorithmic * factor, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(algorithmic * factor / peak, 4),
+                    "traffic": (pmc or {}).get("hbm_bytes_per_launch") if (pmc or {}).get("form", "wino") == form else None,
+                    "traffic_source": "committed rocprofv3 --pmc pass (profiles/pmc_latest.json), not measured in this run",
+                    "kernel": kern, "algorithm": how,
+                    "algorithmic_tflops": round(algorithmic, 2), "executed_per_algorithmic_flop": round(factor, 4),
+                    "algorithmic_over_fp32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC of the direct 3x3 convolution, algorithmic: SURVEY.md 8d)",
                     "share_of_conv_time": round(d["ms"] / total_ms, 4),
                     "by_kernel_ms_per_step": {kname(k): round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))}}
-            if wino:
-                # The kernel evaluates the conv in Winograd F(2x2,3x3) form: 16/36 of the direct form's multiplies reach the matrix
-                # pipe.  `achieved`/`frac` above follow the contract (ALGORITHMIC flops / time); the pipe's own utilisation is below.
-                roof["algorithm"] = "Winograd F(2x2,3x3), fp32: executes 16/36 of the algorithmic MACs on the matrix pipe"
-                roof["executed_mfma_tflops"] = round(achieved * 16.0 / 36.0, 2)
-                roof["frac_executed"] = round(achieved * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS, 4)
     if world > 1:
         torch.distributed.barrier()
 
@@ -246,6 +268,7 @@ def main():
                                     if sisr else f"VIRAttResUNet denoise-syn forward (n_feat 96/192/288, 3 res-blocks, dep_S 5), {args.size}x{args.size}x3 ")
                                    + f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
+                       "arithmetic": "fp32 tensors and accumulation; C->C 3x3 convs: " + FORMS[ops.conv_form()][2],
                        "parallelism": f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), no per-image collective"},
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
