@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--down", action="store_true", help="time the stride-2 down convs (96->192 @256^2, 192->288 @128^2) instead")
     ap.add_argument("--mode", default="res", choices=["dual", "act", "raw", "res", "pre"])
+    ap.add_argument("--ab", default=None, help="VAR=v1,v2,...: interleaved A/B over values of an environment variable the library reads per call")
     args = ap.parse_args()
     torch.manual_seed(0)
     if args.down:
@@ -55,6 +56,23 @@ def main():
         for _ in range(3):
             ops.conv_mfma(x, pw, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if args.ab:
+            var, vals = args.ab.split("=")
+            vals = vals.split(",")
+            res_t = {v: [] for v in vals}
+            for _ in range(args.iters):
+                for v in vals:
+                    os.environ[var] = v
+                    e0.record()
+                    ops.conv_mfma(x, pw, **kw)
+                    e1.record()
+                    e1.synchronize()
+                    res_t[v].append(e0.elapsed_time(e1))
+            flops = 2.0 * n * h * w * c * c * 9
+            for v in vals:
+                t = sorted(res_t[v])
+                print(f"{name:4s} {args.mode:4s} {var}={v:6s} median {t[len(t) // 2]:8.3f} ms  min {t[0]:8.3f} ms  {flops / t[len(t) // 2] / 1e9:7.2f} TFLOP/s", flush=True)
+            continue
         times = []
         for _ in range(args.iters):
             e0.record()

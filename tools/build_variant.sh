@@ -5,7 +5,7 @@ NAME=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=$ROOT/build/variant_$NAME
 mkdir -p $OBJ
-for f in conv_mfma.hip pack.hip small.hip thin.hip wgrad.hip wino.hip wino_row.hip api.cpp; do
+for f in $(cd $ROOT/virnet_amd/csrc && ls *.hip *.cpp); do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip "$@" -c $ROOT/virnet_amd/csrc/$f -o $OBJ/${f%.*}.o &
 done
 wait

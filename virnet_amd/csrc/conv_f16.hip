@@ -24,7 +24,8 @@
 //               DMA (global_load_lds_dwordx4), three taps (one kernel column) per stage, double buffered.
 //   Taps run column by column (dx outer): the MREP+2 input rows a wave needs for one dx are read ONCE and serve all three dy.
 // One barrier per tap group (54 MFMAs per wave at 2x3 blocks); two workgroups per CU cover each other's barriers and epilogues.
-// Epilogue: as conv_mfma.hip (lane = pixel, accumulator quad = 4 consecutive channels, 16-B accesses) after the inverse scale.
+// Epilogue: inverse scale, bias, mask, residual, activation as conv_mfma.hip, after a per-wave LDS turn-around of each 32-channel slab
+// that makes every residual load and store a run of whole 128-B lines.
 #include "common.h"
 #include "../../include/virnet_hip.h"
 #include <cstdlib>
@@ -37,6 +38,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// -DVIRNET_F16_TIMING: wave 0 of every workgroup logs s_memtime at start / after the prologue / after the K loop / at exit plus
+// its HW_ID and XCC_ID into the buffer given to virnet_debug_timing_buffer (tools/f16_timeline.py reads it).
+#ifdef VIRNET_F16_TIMING
+#define TSTAMP(i) do { if (a.tlog && tid == 0) a.tlog[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
 
 struct FArgs {
   const float* x;
@@ -55,7 +63,9 @@ struct FArgs {
   int NP, cout;
   int ntx, nty, ntiles, tiles_per_xcd;
   int in_act;
+  int stagger;
   float in_slope, mask_slope, slope;
+  long long* tlog;
 };
 
 __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
@@ -73,12 +83,16 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h
   }
 }
 
-template <int MREP, int NREP>
+// EPI specialises the epilogue so its loads are straight-line code the compiler can count (a runtime `if (ptr) load` merges into a
+// vmcnt(0) before every store, which serialises the stores on their acknowledgements -- measured: 7 k cycles per slab):
+//   bit 0 = residual, bit 1 = LeakyReLU-derivative mask (backward), one stored tensor; 4 = everything by runtime pointer (two
+//   stored tensors, SFT on the output).
+template <int MREP, int NREP, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
   constexpr int NPIECE = NPIX * 2;                 // (pixel, 8-channel half) staging pieces of one chunk
   constexpr int PPT = (NPIECE + 255) / 256;
-  static_assert(PPT <= 3, "one staged piece per tap group");
+  static_assert(PPT >= 2 && PPT <= 3, "one staged piece per tap group; surplus threads redo piece k-1");
   constexpr int PLANE = NPIX * 32, XB = 2 * PLANE;
   constexpr int WGRP = 3 * NREP * 2048;            // one tap group (three taps) of weight fragments
   constexpr int NDMA = 3 * NREP * 2;               // ... in 1-KB DMA pieces
@@ -103,6 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
   const int tid = threadIdx.x;
+  if (blockIdx.x >= 256 && blockIdx.x < 512) {
+    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(63);
+  }
+  TSTAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -117,15 +135,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int qq = k * 256 + tid;
-    const bool has = qq < NPIECE;
-    const int qc = has ? qq : 0;
-    const int p = qc >> 1, h = qc & 1;
+    const int qc = qq < NPIECE ? qq : qq - 256;      // surplus threads of the last piece redo their previous one (same bytes):
+    const int p = qc >> 1, h = qc & 1;               // no divergent store, the staging code stays one basic block
     const int iy = p / IW, ix = p - iy * IW;
     const int gy = iy0 + iy, gx = ix0 + ix;
-    sinb[k] = has && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    sinb[k] = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
     soff[k] = (unsigned)((gyc * a.W + gxc) * a.Cin + h * 8);
-    sdst[k] = has ? p * 32 + ((h ^ ((p >> 3) & 1)) << 4) : -1;
+    sdst[k] = p * 32 + ((h ^ ((p >> 3) & 1)) << 4);
   }
   const bool in_sft = a.in_mul != nullptr;
   const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + (tid & 1) * 8 : nullptr;
@@ -145,10 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     r1 = sinb[k] ? r1 : z;
     h8 hi, lo;
     split8(r0, r1, hi, lo);
-    if (sdst[k] >= 0) {
-      *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
-      *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
-    }
+    *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
+    *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
   };
 
   // ---- weight DMA: piece q = (tap-in-group, slab, hi|lo), 1 KB = the fragment of one MFMA operand; wave w moves pieces w, w+4, ...
@@ -200,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     for (int k = 0; k < PPT; ++k) stage_store(x_lds, 0, k, r0[k], r1[k]);
   }
   __syncthreads();
+  TSTAMP(1);
 
   h8 ah[2][NREP], al[2][NREP];      // A fragments (weights) of tap t and t+1
   h8 bh[NR], bl[NR];                // B fragments (pixels) of the current kernel column
@@ -216,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   };
 
   // One tap group = kernel column g of chunk c (P = c&1: pixel buffer; weight buffer (P+g)&1; A register set (P + 3g + dy)&1).
+  // A wave issues in order and an MFMA occupies the matrix pipe for 32 cycles: everything else (fragment reads for the next tap, the
+  // staging arithmetic) is threaded BETWEEN the MFMAs with sched_group_barrier so a wave on its own keeps the pipe close to busy.
   auto group = [&](int c, auto pc, auto gc) {
     constexpr int P = decltype(pc)::value, g = decltype(gc)::value;
     const int stage = c * 3 + g;
@@ -223,11 +241,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     char* const xn = x_lds + (P ^ 1) * XB;
     const char* const wb = w_lds + ((P + g) & 1) * WGRP;
     char* const wn = w_lds + ((P + g + 1) & 1) * WGRP;
-    const bool more_w = stage + 1 < nstages, more_x = c + 1 < nch;
-    if (more_w) dma_group(stage + 1, wn);
-    f32x4 s0, s1;
-    if (g < PPT) {
-      const float* const src = ximg + soff[g] + (more_x ? (c + 1) * 16 : c * 16);
+    if (stage + 1 < nstages) dma_group(stage + 1, wn);
+    // one piece of the next chunk's pixels (the last chunk re-stages itself into the idle buffer: no branch in the tap code)
+    const int cn = min(c + 1, nch - 1);
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if constexpr (g < PPT) {
+      const float* const src = ximg + soff[g] + cn * 16;
       s0 = *reinterpret_cast<const f32x4*>(src);
       s1 = *reinterpret_cast<const f32x4*>(src + 4);
     }
@@ -239,19 +258,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     }
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      constexpr int dummy = 0; (void)dummy;
       const int cur = (P + 3 * g + dy) & 1;
       SB();
       // requests for the next tap: its weights (same group) and the input row it needs first; at the last tap of a column the
-      // first rows of the next column (same chunk) -- those registers were last used by tap dy = 1
+      // first rows of the next column (same chunk) -- those registers were last used by tap dy = 1 -- and this group's staging
+      constexpr int NRD = 2 * NREP + 2;
       if (dy < 2) {
         read_a(wb, dy + 1, ah[cur ^ 1], al[cur ^ 1]);
         read_b(xb, MREP + dy, g);
-      } else if (g < 2) {
+      } else {
+        if (g < 2) {
 #pragma unroll
-        for (int r = 0; r < MREP; ++r) read_b(xb, r, g + 1);
+          for (int r = 0; r < MREP; ++r) read_b(xb, r, g + 1);
+        }
+        if constexpr (g < PPT) stage_store(xn, cn, g, s0, s1);
       }
-      SB();
 #pragma unroll
       for (int part = 0; part < 3; ++part)
 #pragma unroll
@@ -262,9 +283,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
             const h8 xv = (part == 1) ? bl[mr + dy] : bh[mr + dy];
             acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[mr][nr], 0, 0, 0);
           }
+      // interleave: one MFMA, then one LDS read (taps 0, 1) or a handful of staging VALU ops (tap 2)
+      constexpr int NM = 3 * MREP * NREP;
+      if (dy < 2) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (g < 2 && i < 2 * MREP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
+        if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+      }
     }
     SB();
-    if (g < PPT && more_x) stage_store(xn, c + 1, g, s0, s1);
     __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
@@ -276,76 +313,148 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     group(c + 1, I1{}, I0{}); group(c + 1, I1{}, I1{}); group(c + 1, I1{}, I2{});
   }
   if (c < nch) { group(c, I0{}, I0{}); group(c, I0{}, I1{}); group(c, I0{}, I2{}); }
+  TSTAMP(2);
 
-  // ---- epilogue: lane = pixel (ox0 + l31), accumulator quad g = 4 consecutive channels 8g + 4*lhi + (0..3)
+  // ---- epilogue
+  // Each wave turns its own MREP x 32 pixel x 32 channel slab around through a private LDS region ([pixel][32 channels], 16 B of
+  // padding per pixel; the pixel / weight buffers are free after the last barrier): lane = (pixel j>>3 of 8, channel quad j&7), so
+  // one store / residual-load instruction covers 8 pixels x 128 contiguous bytes instead of 32 scattered 32-B pieces.
   const int nbase = cb * NB;
-  const int px = ox0 + l31;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
-  const float* const rimg = a.res ? a.res + img_off : nullptr;
-  const float* const mimg = a.mask ? a.mask + img_off : nullptr;
-  float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
-  float* const yact = a.y_act ? a.y_act + img_off : nullptr;
-  const float* const mulp = a.mul ? a.mul + (size_t)img * C : nullptr;
-  const float* const addp = a.add ? a.add + (size_t)img * C : nullptr;
-  unsigned eo[MREP];
-  bool ok[MREP];
+  constexpr int TPIX = 144, NIT = MREP * 4;          // 8 pixels per pass
+  char* const tbuf = smem + wave * (MREP * 32 * TPIX);
+  const int cq = lane & 7, psub = lane >> 3;
+  unsigned eoff[NIT];
+  bool eok[NIT];
 #pragma unroll
-  for (int mr = 0; mr < MREP; ++mr) {
-    const int oy = oy0 + wave * MREP + mr;
-    ok[mr] = oy < a.H && px < a.W;
-    eo[mr] = (unsigned)(min(oy, a.H - 1) * a.W + min(px, a.W - 1)) * (unsigned)C;
+  for (int it = 0; it < NIT; ++it) {
+    const int pix = it * 8 + psub;
+    const int oy = oy0 + wave * MREP + (pix >> 5), ox = ox0 + (pix & 31);
+    eok[it] = oy < a.H && ox < a.W;
+    eoff[it] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)(nbase + cq * 4);
   }
+  auto turn_in = [&](int nr) {
 #pragma unroll
-  for (int nr = 0; nr < NREP; ++nr) {
-    f32x4 bias[4], inv[4], rv[4][MREP], mv[4][MREP];
-    unsigned off[4][MREP];
-    int cog[4];
+    for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co = nbase + nr * 32 + 8 * g + 4 * lhi;
-      cog[g] = co;
-      bias[g] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
-      inv[g] = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(tbuf + (mr * 32 + l31) * TPIX + (8 * g + 4 * lhi) * 4) =
+            f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
+  };
+  auto mask4 = [&](f32x4 v, f32x4 m) {
+    return f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
+                 m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+  };
+  if constexpr (EPI < 4) {
+    // ONE stored tensor, straight-line code: every load is requested before the stores that follow it and none sits behind a branch,
+    // so the compiler's counted vmcnt waits never include a store acknowledgement.
+    constexpr bool RES = (EPI & 1) != 0, MASK = (EPI & 2) != 0;
+    const float* const rimg = a.res + img_off;
+    const float* const mimg = a.mask + img_off;
+    float* const y = (a.y_act ? a.y_act : a.y_raw) + img_off;
+    const float slope_eff = a.y_act ? a.slope : 1.f;                        // max(v, 1*v) == v: raw store
+    const float* const bp = a.bias ? a.bias : a.inv_scale;                  // (no bias: read something valid, scale it by 0)
+    const float hb = a.bias ? 1.f : 0.f;
+    // gfx950 counts loads and stores on ONE counter that the compiler must treat as out of order once both kinds are pending: a
+    // load consumed after a store was issued costs a vmcnt(0), i.e. the store's acknowledgement.  So every load of the tile is
+    // requested AND waited for before the first store (EPI 3 cannot hold two operand tiles: its mask comes slab by slab).
+    constexpr bool HOIST = EPI == 1 || EPI == 2;
+    f32x4 bias4[NREP], inv4[NREP], op1[HOIST ? NREP : 1][NIT];
+    const float* const op1p = RES ? rimg : mimg;
 #pragma unroll
-      for (int mr = 0; mr < MREP; ++mr) {
-        off[g][mr] = eo[mr] + (unsigned)co;
-        rv[g][mr] = rimg ? *reinterpret_cast<const f32x4*>(rimg + off[g][mr]) : zero4;
-        if (mimg) mv[g][mr] = *reinterpret_cast<const f32x4*>(mimg + off[g][mr]);
+    for (int nr = 0; nr < NREP; ++nr) {
+      inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nbase + nr * 32 + cq * 4);
+      bias4[nr] = *reinterpret_cast<const f32x4*>(bp + nbase + nr * 32 + cq * 4);
+      if (HOIST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) op1[nr][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
       }
     }
+    TSTAMP(6);
+    turn_in(0);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 mul = f32x4{1.f, 1.f, 1.f, 1.f}, add = zero4;
-      if (mulp) {
-        mul = *reinterpret_cast<const f32x4*>(mulp + cog[g]);
-        add = *reinterpret_cast<const f32x4*>(addp + cog[g]);
+    for (int nr = 0; nr < NREP; ++nr) {
+      asm volatile("" ::"v"(inv4[nr]), "v"(bias4[nr]));
+      if (HOIST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" ::"v"(op1[nr][it]));
       }
+    }
+#endif
 #pragma unroll
-      for (int mr = 0; mr < MREP; ++mr) {
-        f32x4 v = f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]} * inv[g] + bias[g];
-        if (mimg) {
-          const f32x4 m = mv[g][mr];
-          v = f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
-                    m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+    for (int nr = 0; nr < NREP; ++nr) {
+      f32x4 mv[NIT], rv[NIT];
+      if (EPI == 3) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          mv[it] = *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32);
+          rv[it] = *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
         }
-        v += rv[g][mr];
-        if (ok[mr]) {
-          if (yraw) *reinterpret_cast<f32x4*>(yraw + off[g][mr]) = v;
-          if (yact) *reinterpret_cast<f32x4*>(yact + off[g][mr]) = lrelu4(v * mul + add, a.slope);
+      }
+      if (nr > 0) turn_in(nr);
+      const f32x4 b4 = bias4[nr] * hb;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + (it * 8 + psub) * TPIX + cq * 16) * inv4[nr] + b4;
+        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[HOIST ? nr : 0][it]);
+        if (RES) v += EPI == 3 ? rv[it] : op1[HOIST ? nr : 0][it];
+        if (eok[it]) *reinterpret_cast<f32x4*>(y + eoff[it] + nr * 32) = lrelu4(v, slope_eff);
+      }
+      if (nr == 0) TSTAMP(7);
+    }
+  } else {
+    // generic form (two stored tensors and / or SFT on the output): optional operands by runtime pointer
+    const float* const rimg = a.res ? a.res + img_off : nullptr;
+    const float* const mimg = a.mask ? a.mask + img_off : nullptr;
+    float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+    float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      const int co = nbase + nr * 32 + cq * 4;
+      const f32x4 inv4 = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
+      const f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
+      f32x4 mul4 = f32x4{1.f, 1.f, 1.f, 1.f}, add4 = zero4;
+      if (a.mul) {                                           // SFT on the output (AttResUNet.py:57-58): SISR down path
+        mul4 = *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + co);
+        add4 = *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + co);
+      }
+      f32x4 rv[NIT], mv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        rv[it] = rimg ? *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32) : zero4;
+        if (mimg) mv[it] = *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32);
+      }
+      turn_in(nr);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + (it * 8 + psub) * TPIX + cq * 16) * inv4 + bias4;
+        if (mimg) v = mask4(v, mv[it]);
+        v += rv[it];
+        if (eok[it]) {
+          if (yraw) *reinterpret_cast<f32x4*>(yraw + eoff[it] + nr * 32) = v;
+          if (yact) *reinterpret_cast<f32x4*>(yact + eoff[it] + nr * 32) = lrelu4(v * mul4 + add4, a.slope);
         }
       }
     }
   }
+#ifdef VIRNET_F16_TIMING
+  TSTAMP(3);
+  if (a.tlog && tid == 0) {
+    a.tlog[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+    a.tlog[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
+  }
+#endif
 }
 
-template <int MREP, int NREP>
+template <int MREP, int NREP, int EPI>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int LDS = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);
   static unsigned long long attr_done = 0;
-  auto kern = conv_f16_kernel<MREP, NREP>;
+  auto kern = conv_f16_kernel<MREP, NREP, EPI>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16): %s", hipGetErrorString(e));
@@ -403,6 +512,11 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout,
 
 }  // namespace
 
+#ifdef VIRNET_F16_TIMING
+static long long* g_tlog = nullptr;
+extern "C" void virnet_debug_timing_buffer(void* p) { g_tlog = static_cast<long long*>(p); }
+#endif
+
 extern "C" size_t virnet_f16_weight_floats(int cin_pad, int n_pad) { return (size_t)n_pad + (size_t)n_pad * cin_pad * 9; }
 
 extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream) {
@@ -435,6 +549,10 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   k.in_mul = d->in_mul; k.in_add = d->in_add; k.mask = d->mask; k.y_raw = d->y_raw; k.y_act = d->y_act;
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.NP = d->n_pad; k.cout = d->cout;
   k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
+#ifdef VIRNET_F16_TIMING
+  k.tlog = g_tlog;
+#endif
+  { const char* const env_s = getenv("VIRNET_F16_STAGGER"); k.stagger = env_s ? atoi(env_s) : 0; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nb = d->cout / 32;
   const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
@@ -443,7 +561,15 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   const int nrep = (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
   int mrep = (tiles8 * (nb / nrep) >= 1024) ? 2 : 1;
   if (forced_m == 1 || forced_m == 2) mrep = forced_m;
-#define VIRNET_F16_CASE(M_, N_) if (mrep == M_ && nrep == N_) return launch<M_, N_>(k, st)
+  const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
+#define VIRNET_F16_CASE(M_, N_)                       \
+  if (mrep == M_ && nrep == N_) {                     \
+    if (epi == 0) return launch<M_, N_, 0>(k, st);    \
+    if (epi == 1) return launch<M_, N_, 1>(k, st);    \
+    if (epi == 2) return launch<M_, N_, 2>(k, st);    \
+    if (epi == 3) return launch<M_, N_, 3>(k, st);    \
+    return launch<M_, N_, 4>(k, st);                  \
+  }
   VIRNET_F16_CASE(2, 3); VIRNET_F16_CASE(2, 2); VIRNET_F16_CASE(2, 1);
   VIRNET_F16_CASE(1, 3); VIRNET_F16_CASE(1, 2); VIRNET_F16_CASE(1, 1);
 #undef VIRNET_F16_CASE
