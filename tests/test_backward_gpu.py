@@ -135,6 +135,8 @@ def _elbo(mu, sigma, im_noisy, im_gt, sigma_gt, eps2=1e-6, var_window=7):
     (dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input"), (2, 3, 32, 32)),
     (dict(im_chn=1, sigma_chn=1, n_feat=[64, 128], dep_S=3, n_resblocks=1, noise_cond=False, extra_mode="Null"), (2, 1, 18, 22)),
     (dict(im_chn=3, sigma_chn=3, n_feat=[64, 96], dep_S=3, n_resblocks=1, noise_cond=True, extra_mode="Input"), (1, 3, 21, 19)),
+    # BASELINE configs[4]'s patch size (train_denoising_syn.py, 128x128) at a batch autograd through the oracle finishes in seconds
+    (dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input"), (2, 3, 128, 128)),
 ])
 def test_training_step_gradients_match_autograd_oracle(cfg, shape):
     """One ELBO step (train_denoising_syn.py:176-179): every parameter gradient of the HIP backward against torch autograd
@@ -163,17 +165,69 @@ def test_training_step_gradients_match_autograd_oracle(cfg, shape):
     assert abs(float(loss) - float(loss_r)) <= 1e-4 * abs(float(loss_r))
     # LeakyReLU is not smooth: a pre-activation within fp32 re-association noise of 0 can land on the other side of the kink
     # than in the oracle and changes that ONE element's derivative from 1 to 0.2 (seen: 1 flip in 36 864 elements of one layer
-    # of the full config -> 5.7e-3 on that layer's gradient, everything else 2e-6; tools/dbg_bwd2.py).  So: every parameter
-    # within 2e-2 of its gradient's scale (a wrong kernel is off by O(1)), and the typical parameter at fp32 noise level.
-    errs = []
+    # of the full config -> 5.7e-3 on the MAX error of that layer's gradient).  A flip is a sparse perturbation: it moves the
+    # maximum, not the bulk.  So every parameter gradient is held to fp32 noise in its MEDIAN element (a systematic error -- a
+    # wrong scale of 1 % on a bias gradient, a missing tap, a transposed channel -- moves the median by ~1e-2 of the scale), to
+    # 2e-2 in its worst element, and only a minority of tensors may carry a flip's footprint at all.
+    errs, meds = [], []
     for name, p in net.named_parameters():
         g, gr = p.grad.cpu(), ref[name].grad
         assert g.shape == gr.shape, name
-        scale = float(gr.abs().max())
-        err = float((g - gr).abs().max()) / max(scale, 1e-12)
+        scale = max(float(gr.abs().max()), 1e-12)
+        err = float((g - gr).abs().max()) / scale
+        med = float((g - gr).abs().median()) / scale
         errs.append(err)
+        meds.append(med)
+        assert med <= 2e-5, (name, med, err, scale)
         assert err <= 2e-2, (name, err, scale)
-    assert float(np.median(errs)) <= 1e-3 and float(np.min(errs)) <= 2e-5, (np.median(errs), np.min(errs))
+    errs = np.asarray(errs)
+    assert float(np.mean(errs > 1e-4)) <= 0.34, (float(np.mean(errs > 1e-4)), errs.max())
+    assert float(np.median(errs)) <= 1e-4 and float(np.min(errs)) <= 2e-5, (np.median(errs), np.min(errs))
+
+
+def test_train_step_config4_shape_is_mean_of_per_image_steps():
+    """BASELINE configs[4]'s shape, [32,3,128,128] through forward + ELBO + backward (train_denoising_syn.py:171-184), by a
+    size-independent property: the loss is a mean over the batch and no op couples samples, so every parameter
+    gradient of the batch step equals the mean of the 32 single-image steps -- up to the fp32 atomics' summation order in the
+    weight-gradient kernel (and bit for bit in the forward)."""
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    cfg = dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input")
+    net = VIRAttResUNet(**cfg)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5))
+    net = net.cuda().train()
+    n = 32
+    gt = synth_images(n, 3, 128, 128, seed=1).cuda()
+    sig_gt = (0.02 + 0.25 * synth_images(n, 1, 128, 128, seed=2).cuda()) ** 2
+    noisy = gt + (synth_images(n, 3, 128, 128, seed=3).cuda() - 0.5) * 0.4
+    params = dict(net.named_parameters())
+
+    def step(sl):
+        for p in params.values():
+            p.grad = None
+        mu, sigma = net(noisy[sl].contiguous())
+        loss = _elbo(mu, sigma, noisy[sl], gt[sl], sig_gt[sl], eps2=1e-2)
+        loss.backward()
+        return float(loss), mu.detach(), {k: p.grad.double().clone() for k, p in params.items()}
+
+    loss_b, mu_b, g_b = step(slice(0, n))
+    acc = {k: torch.zeros_like(v) for k, v in g_b.items()}
+    loss_sum = 0.0
+    for i in range(n):
+        li, mi, gi = step(slice(i, i + 1))
+        assert torch.equal(mi[0], mu_b[i])                         # batch independence of the forward, bit for bit
+        loss_sum += li
+        for k in acc:
+            acc[k] += gi[k]
+    assert abs(loss_b - loss_sum / n) <= 1e-5 * abs(loss_b)
+    worst = 0.0
+    for k in acc:
+        ref = acc[k] / n
+        scale = max(float(ref.abs().max()), 1e-12)
+        err = float((g_b[k] - ref).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-4, (k, err, scale)
+    assert all(torch.isfinite(v).all() for v in g_b.values()) and worst > 0.0
 
 
 def test_optimizer_step_and_repack():

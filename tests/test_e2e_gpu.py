@@ -116,6 +116,53 @@ def test_full_size_properties(manifest):
     assert torch.isfinite(mu).all() and float(sigma.min()) >= 1e-10 and float(sigma.max()) <= 1e2 * (1 + 1e-6)
 
 
+def test_metric_shape_properties_256(manifest):
+    """BASELINE configs[2]'s per-GPU shard -- the shape bench.py times: [32,3,256,256] through the denoise-syn net.  Size-independent
+    properties: determinism, batch independence (bit for bit: no cross-sample op), batch-order permutation, output
+    ranges; and the three convolution forms (split-fp16 default, Winograd, fp32 direct) agree at this size where the large-grid
+    tile / workgroup forms are the auto-selected ones (8-row tiles, 8-wave Winograd workgroups)."""
+    import os
+    net, _, _, _ = get_net(manifest, "syn")
+    x = synth_images(32, 3, 256, 256).cuda()
+    with torch.no_grad():
+        mu, sigma = net(x)
+        mu2, sigma2 = net(x)
+        assert torch.equal(mu, mu2) and torch.equal(sigma, sigma2)
+        for i in (0, 13, 31):
+            mi, si = net(x[i:i + 1].contiguous())
+            assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
+        perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+        mup, _ = net(x[perm].contiguous())
+        assert torch.equal(mup, mu[perm])
+        assert torch.isfinite(mu).all() and float(sigma.min()) >= 1e-10 and float(sigma.max()) <= 1e2 * (1 + 1e-6)
+        old = os.environ.get("VIRNET_CONV_FORM")
+        try:
+            for form in ("wino", "direct"):
+                os.environ["VIRNET_CONV_FORM"] = form
+                mu_f, sig_f = net(x)
+                assert float((mu_f - mu).abs().max()) <= TIGHT, form
+                assert float((sig_f - sigma).abs().max()) <= TIGHT, form
+        finally:
+            if old is None:
+                os.environ.pop("VIRNET_CONV_FORM", None)
+            else:
+                os.environ["VIRNET_CONV_FORM"] = old
+
+
+@pytest.mark.parametrize("form", ["f16x3", "wino"])
+def test_denoise_vs_oracle_256_pair(manifest, monkeypatch, form):
+    """The metric's image size against the CPU oracle at a batch it finishes in seconds: [2,3,256,256]."""
+    monkeypatch.setenv("VIRNET_CONV_FORM", form)
+    net, sd, cfg, _ = get_net(manifest, "syn")
+    x = synth_images(2, 3, 256, 256)
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+    with torch.no_grad():
+        mu_ref, sig_ref = cpu_ref.virnet_denoise(sd, x, **kw)
+        mu, sigma = net(x.cuda())
+    assert float((mu.cpu() - mu_ref).abs().max()) <= TIGHT
+    assert float((sigma.cpu() - sig_ref).abs().max()) <= TIGHT
+
+
 def test_outputs_are_fresh_and_module_api(manifest):
     """Callers mutate results in place (scripts/testing_demo.py:95); .train()/.eval() are numerically identical."""
     net, _, _, _ = get_net(manifest, "syn")

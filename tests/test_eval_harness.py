@@ -103,3 +103,54 @@ def test_psnr_parity_cbsd68_sigma50(manifest):
         assert abs(p - p_ref) <= 0.01, (idx, p, p_ref)
         assert float((mu.cpu() - mu_ref).abs().max()) <= 1e-3
         assert int(np.abs(den.astype(int) - den_ref.astype(int)).max()) <= 1      # identical up to rounding ties
+
+
+@pytest.mark.gpu
+def test_niid_table_cbsd68_hip_vs_oracle(manifest):
+    """BASELINE configs[0] (denoising_virnet_syn.py, niid noise on CBSD68): the evaluation-table code path the CLI
+    tools/denoising_syn_eval.py runs (virnet_amd.eval.denoise_table: one shared rng, three variance maps, unclipped noise, uint8
+    PSNR) over the three CBSD68 fixture images, HIP forward vs CPU oracle forward on identical synthetic weights: every per-image
+    PSNR within 0.01 dB.  (The product has no CPU path, so configs[0]'s 'CPU plumbing' run is honoured on the GPU box.)"""
+    from oracle import cpu_ref
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_state_dict
+    cfg = dict(manifest["configs"]["syn"]); cfg.pop("kind")
+    net = VIRAttResUNet(**cfg)
+    sd = synth_state_dict({k: tuple(s) for k, s in manifest["shapes"]["syn"].items()})
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+
+    def to_x(noisy):
+        return torch.from_numpy(np.ascontiguousarray(noisy.transpose(2, 0, 1)[np.newaxis]))
+
+    def fwd_hip(noisy):
+        with torch.no_grad():
+            return net(to_x(noisy).cuda())[0].squeeze(0).cpu().numpy().transpose(1, 2, 0)
+
+    def fwd_ref(noisy):
+        with torch.no_grad():
+            return cpu_ref.virnet_denoise(sd, to_x(noisy), **kw)[0].squeeze(0).numpy().transpose(1, 2, 0)
+
+    data = [os.path.join(GOLDEN, "cbsd68") + ":png"]
+    rows = veval.denoise_table(fwd_hip, data, "niid", with_ssim=False)
+    rows_ref = veval.denoise_table(fwd_ref, data, "niid", with_ssim=False)
+    assert [r["case"] for r in rows] == [1, 2, 3] and all(r["images"] == 3 for r in rows)
+    for r, rr in zip(rows, rows_ref):
+        for p, pr in zip(r["per_image_psnr"], rr["per_image_psnr"]):
+            assert abs(p - pr) <= 0.01, (r["case"], p, pr)
+        assert abs(r["psnr"] - rr["psnr"]) <= 0.01
+
+
+def test_denoise_table_plumbing_cpu():
+    """The table code itself (no GPU): identity 'denoiser' over the fixtures reproduces the noisy-image PSNR for both noise types,
+    the rng stream is shared across cases (case 2 differs from a fresh-rng case 2), rows are ordered like the script's."""
+    data = [os.path.join(GOLDEN, "cbsd68") + ":png"]
+    rows = veval.denoise_table(lambda noisy: noisy, data, "iid", with_ssim=False)
+    assert [r["case"] for r in rows] == [15, 25, 50]
+    assert rows[0]["psnr"] > rows[1]["psnr"] > rows[2]["psnr"]
+    assert abs(rows[2]["psnr"] - 14.9) < 1.0                       # sigma 50 on uint8: 20 log10(255/50) = 14.15 dB before clipping gains
+    rows_n = veval.denoise_table(lambda noisy: noisy, data, "niid", with_ssim=False)
+    assert [r["case"] for r in rows_n] == [1, 2, 3] and all(10.0 < r["psnr"] < 30.0 for r in rows_n)
+    with pytest.raises(ValueError):
+        veval.denoise_table(lambda n: n, data, "poisson")

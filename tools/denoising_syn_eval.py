@@ -13,7 +13,6 @@ is then only a plumbing check.  Needs a ROCm device: the product path has no CPU
     python tools/denoising_syn_eval.py --data tests/golden/cbsd68:png --noise_type iid [--ckpt_path model_state_niidgauss.pt]
 """
 import argparse
-import glob
 import os
 import sys
 
@@ -48,33 +47,18 @@ def main():
     sd = load_state(args.ckpt_path, {k: tuple(v.shape) for k, v in net.state_dict().items()})
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
-    forward = lambda x: net(x.cuda())[0].cpu()                                                # noqa: E731
 
-    rng = np.random.default_rng(seed=veval.NOISE_SEED)
-    cases = veval.niid_sigma_maps(rng) if args.noise_type == "niid" else list(veval.IID_SIGMAS)
-    for spec in args.data:
-        folder, ext = spec.rsplit(":", 1)
-        files = sorted(glob.glob(os.path.join(folder, "*." + ext)))
-        if not files:
-            print(f"{folder}: no *.{ext} files, skipped")
-            continue
-        for jj, case in enumerate(cases):
-            psnr = ssim = 0.0
-            for f in files:
-                gt = veval.imread_rgb_uint8(f)
-                h, w = gt.shape[:2]
-                sigma = (veval.resize_nearest_exact(case, h, w).astype(np.float32) if args.noise_type == "niid"
-                         else np.ones([h, w], dtype=np.float32) * (case / 255.0))
-                noise = rng.standard_normal(size=gt.shape) * sigma[:, :, np.newaxis]
-                noisy = veval.img_as_float32(gt) + noise.astype(np.float32)
-                x = torch.from_numpy(np.ascontiguousarray(noisy.transpose(2, 0, 1)[np.newaxis]))
-                with torch.no_grad():
-                    mu = forward(x)
-                den = veval.img_as_ubyte(np.clip(mu.squeeze(0).numpy().transpose(1, 2, 0), 0.0, 1.0))
-                psnr += veval.calculate_psnr(den, gt, border=0)
-                ssim += veval.calculate_ssim(den, gt, border=0)
-            tag = f"case: {jj + 1:d}" if args.noise_type == "niid" else f"sigma: {case:d}"
-            print(f"Dataset: {os.path.basename(folder.rstrip('/')):8s}, {tag}, PSNR: {psnr / len(files):5.2f}, SSIM: {ssim / len(files):6.4f}", flush=True)
+    def forward(noisy_hwc):
+        x = torch.from_numpy(np.ascontiguousarray(noisy_hwc.transpose(2, 0, 1)[np.newaxis]))
+        with torch.no_grad():
+            return net(x.cuda())[0].squeeze(0).cpu().numpy().transpose(1, 2, 0)
+
+    rows = veval.denoise_table(forward, args.data, args.noise_type)
+    if not rows:
+        print("no images found under", args.data)
+    for r in rows:
+        tag = f"case: {r['case']:d}" if args.noise_type == "niid" else f"sigma: {r['case']:d}"
+        print(f"Dataset: {r['dataset']:8s}, {tag}, PSNR: {r['psnr']:5.2f}, SSIM: {r['ssim']:6.4f}", flush=True)
 
 
 if __name__ == "__main__":

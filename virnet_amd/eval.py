@@ -168,3 +168,41 @@ def calculate_ssim(im1: np.ndarray, im2: np.ndarray, border: int = 0, ycbcr: boo
 def calculate_psnr_y(im1: np.ndarray, im2: np.ndarray, border: int = 0) -> float:
     """PSNR on the Y channel (utils/util_image.py:68-89 with ycbcr=True; the SISR scripts use border = sf**2)."""
     return calculate_psnr(rgb2y_uint8(im1), rgb2y_uint8(im2), border)
+
+
+def denoise_table(forward, data: Sequence[str], noise_type: str = "niid", rng: "np.random.Generator | None" = None,
+                  with_ssim: bool = True) -> List[dict]:
+    """The PSNR / SSIM table of scripts/denoising_virnet_syn.py:93-156 for any ``forward(noisy float32 HWC) -> mu float32 HWC``.
+
+    ``data`` = ["folder:ext", ...] in the script's order.  ONE Generator (seed 1000) is shared by every dataset and case (the niid
+    mixture maps consume its first draws), noisy = img_as_float32(uint8) + float32(noise) unclipped, output = img_as_ubyte(clip(mu)).
+    Returns one row per (dataset, case): {"dataset", "case", "psnr", "ssim", "images", "per_image_psnr"}."""
+    import glob
+    import os
+    if noise_type not in ("iid", "niid"):
+        raise ValueError(f"noise_type {noise_type!r}: expected iid or niid")
+    rng = np.random.default_rng(seed=NOISE_SEED) if rng is None else rng
+    cases = niid_sigma_maps(rng) if noise_type == "niid" else list(IID_SIGMAS)
+    rows = []
+    for spec in data:
+        folder, ext = spec.rsplit(":", 1)
+        files = sorted(glob.glob(os.path.join(folder, "*." + ext)))
+        if not files:
+            continue
+        for jj, case in enumerate(cases):
+            psnrs, ssims = [], []
+            for f in files:
+                gt = imread_rgb_uint8(f)
+                h, w = gt.shape[:2]
+                sigma = (resize_nearest_exact(case, h, w).astype(np.float32) if noise_type == "niid"
+                         else np.ones([h, w], dtype=np.float32) * (case / 255.0))
+                noise = rng.standard_normal(size=gt.shape) * sigma[:, :, np.newaxis]
+                noisy = img_as_float32(gt) + noise.astype(np.float32)
+                den = img_as_ubyte(np.clip(forward(noisy), 0.0, 1.0))
+                psnrs.append(calculate_psnr(den, gt, border=0))
+                if with_ssim:
+                    ssims.append(calculate_ssim(den, gt, border=0))
+            rows.append({"dataset": os.path.basename(folder.rstrip("/")), "case": (jj + 1) if noise_type == "niid" else int(case),
+                         "psnr": float(np.mean(psnrs)), "ssim": float(np.mean(ssims)) if ssims else float("nan"),
+                         "images": len(files), "per_image_psnr": psnrs})
+    return rows
