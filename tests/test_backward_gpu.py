@@ -178,7 +178,7 @@ def test_training_step_gradients_match_autograd_oracle(cfg, shape):
         med = float((g - gr).abs().median()) / scale
         errs.append(err)
         meds.append(med)
-        assert med <= 2e-5, (name, med, err, scale)
+        assert med <= 5e-5, (name, med, err, scale)
         assert err <= 2e-2, (name, err, scale)
     errs = np.asarray(errs)
     assert float(np.mean(errs > 1e-4)) <= 0.34, (float(np.mean(errs > 1e-4)), errs.max())

@@ -98,3 +98,25 @@ def test_gradient_reducer_single_process_is_identity():
         red.push({p[0]: torch.ones(4, 4)})
         out = red.finish()
         assert torch.equal(out[p[0]], torch.ones(4, 4)) and torch.equal(out[p[1]], torch.arange(3.0))
+
+
+def test_reducer_gradients_do_not_alias_buckets():
+    """finish() must not hand out views of the flat buckets -- autograd adopts what it gets as p.grad, and the next
+    step's push() would overwrite it before `p.grad += new` runs (2x gradients with zero_grad(set_to_none=False) / accumulation)."""
+    import torch
+    from virnet_amd.dist import GradientReducer
+    ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+    red = GradientReducer(ps, bucket_bytes=16)
+    for step in range(3):
+        red.start()
+        red.push({ps[0]: torch.full((5,), 1.0 + step), ps[1]: torch.full((3, 2), 10.0 + step)})
+        out = red.finish()
+        for p in ps:                                       # what AccumulateGrad does: adopt on the first step, accumulate afterwards
+            if p.grad is None:
+                p.grad = out[p]
+            else:
+                p.grad += out[p]
+        bucket_ptrs = {b.data_ptr() for b in red._buckets}
+        assert all(out[p].data_ptr() not in bucket_ptrs for p in ps)
+    assert torch.equal(ps[0].grad, torch.full((5,), 1.0 + 2.0 + 3.0))          # accumulation over three steps, not 2x the last
+    assert torch.equal(ps[1].grad, torch.full((3, 2), 10.0 + 11.0 + 12.0))

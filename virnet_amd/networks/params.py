@@ -62,6 +62,13 @@ class ConvParam(nn.Module):
             self._thin_key = key
         return self._thin
 
+    def invalidate(self) -> None:
+        """Drop the cached packings.  They follow the parameter's storage and ``_version``; a write through ``.data`` (EMA helpers,
+        weight clipping) changes neither, so call this (or ``net.apply(lambda m: getattr(m, 'invalidate', lambda: None)())``) after one."""
+        self._pack = None
+        self._dgrad = None
+        self._thin = None
+
     def forward(self, *args, **kwargs):  # pragma: no cover - guard
         raise RuntimeError("ConvParam holds parameters only; the convolution runs inside libvirnet_hip "
                            "(call the enclosing network's forward)")

@@ -197,6 +197,9 @@ class DenoiseFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, *params):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("VIRAttResUNet: a gradient with respect to the input image is not implemented (the reference's training "
+                               "never asks for one, train_denoising_syn.py:171-184); pass x.detach()")
         x = _prep(x, net.SNet.in_channels)          # raises on CPU / wrong dtype before anything touches a device
         with torch.no_grad(), torch.cuda.device(x.device):
             mu, sigma, tape = denoise_forward_train(net, x)
@@ -215,7 +218,7 @@ class DenoiseFunction(torch.autograd.Function):
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)      # gradients produced on the side stream are consumed after this
             if reducer is not None:
-                grads = reducer.finish()                  # averaged over the ranks; views of the flat buckets
+                grads = reducer.finish()                  # averaged over the ranks (copies of the flat buckets' slices)
         ctx.tape = None
         return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
