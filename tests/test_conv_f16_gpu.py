@@ -166,3 +166,40 @@ def test_f16x3_randomised_sweep_against_direct_kernel(monkeypatch):
                     worst = max(worst, e)
                     assert e <= 5e-5, (case, form, cin, cout, n, h, w, opts, e)
     assert worst > 0.0
+
+
+@pytest.mark.parametrize("c,cout,h,w,n", [(96, 3, 12, 36, 2), (64, 1, 9, 40, 1), (64, 3, 16, 16, 3), (96, 3, 40, 70, 1), (32, 2, 5, 33, 2)])
+def test_f16x3_planar_store(c, cout, h, w, n):
+    """Few-output-channel exits on the split-fp16 kernel (one slab, planar store): tail conv + crop + `+ x_in` (AttResUNet.py:139,173),
+    the same through a nearest x2 residual (VIRNet.py:83), SNet's last conv with exp(clamp(.)) (DnCNN.py:29, VIRNet.py:43)."""
+    cp = make_conv(c, cout, seed=40)
+    x = rnd(n, c, h, w, seed=41)
+    v = F.conv2d(x, cp.weight.detach(), cp.bias.detach(), padding=1)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.f16 is not None
+    assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w)).cpu(), v) <= TOL
+    ch, cw = h - 2, w - 3
+    xin = rnd(n, cout, ch, cw, seed=42)
+    assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (ch, cw), op=nat.NCHW_ADD, res=xin.cuda()).cpu(), v[..., :ch, :cw] + xin) <= TOL
+    if h % 2 == 0 and w % 2 == 0:
+        xlr = rnd(n, cout, h // 2, w // 2, seed=43)
+        ref = v + F.interpolate(xlr, scale_factor=2, mode="nearest")
+        assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w), op=nat.NCHW_ADD, res=xlr.cuda(), res_sf=2).cpu(), ref) <= TOL
+    ref = torch.exp(torch.clamp(v, min=-0.5, max=0.7))
+    assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(-0.5, 0.7)).cpu(), ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(4, 96, 24, 40, 2), (3, 64, 17, 33, 1), (7, 96, 8, 70, 2)])
+def test_f16x3_entry_conv_single_chunk(cin, cout, h, w, n):
+    """Few-input-channel entries (AttResUNet.head 4/7 -> 96, DnCNN.conv1 3 -> 64): one 16-channel chunk, raw and activated stores."""
+    cp = make_conv(cin, cout, seed=44)
+    x = rnd(n, cin, h, w, seed=45)
+    raw_ref, act_ref = cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach(), slope=0.25)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.f16 is not None and pw.cin_pad == 16
+    xr = nhwc(F.pad(x, (0, 0, 0, 0, 0, 16 - cin)))
+    raw, _ = ops.conv_mfma(xr, pw, want_raw=True)
+    _, act = ops.conv_mfma(xr, pw, want_raw=False, want_act=True, slope=0.25)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL

@@ -63,8 +63,8 @@ struct FArgs {
   int NP, cout;
   int ntx, nty, ntiles, tiles_per_xcd;
   int in_act;
-  int stagger;
-  float in_slope, mask_slope, slope;
+  int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
+  float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
   long long* tlog;
 };
 
@@ -86,7 +86,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h
 // EPI specialises the epilogue so its loads are straight-line code the compiler can count (a runtime `if (ptr) load` merges into a
 // vmcnt(0) before every store, which serialises the stores on their acknowledgements -- measured: 7 k cycles per slab):
 //   bit 0 = residual, bit 1 = LeakyReLU-derivative mask (backward), one stored tensor; 4 = everything by runtime pointer (two
-//   stored tensors, SFT on the output).
+//   stored tensors, SFT on the output); 5 = planar NCHW store of <= 32 channels with crop and `+ x_in` / exp(clamp) (NREP = 1:
+//   AttResUNet.tail, AttResUNet.py:139,173; DnCNN.conv_last, DnCNN.py:29 + VIRNet.py:43; KernelNet.tail, KNet.py:49).
 template <int MREP, int NREP, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
@@ -117,9 +118,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   const int iy0 = oy0 - 1, ix0 = ox0 - 1;
 
   const int tid = threadIdx.x;
-  if (blockIdx.x >= 256 && blockIdx.x < 512) {
-    for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(63);
-  }
   TSTAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -316,6 +314,41 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   TSTAMP(2);
 
   // ---- epilogue
+  if constexpr (EPI == 5) {
+    // planar store: lane = pixel (ox0 + l31), register r = channel (r&3) + 8*(r>>2) + 4*lhi; 32 consecutive x per channel = 128-B runs
+    static_assert(NREP == 1, "planar store is for <= 32 channels");
+    const int px = ox0 + l31;
+    const size_t plane = (size_t)a.crop_h * a.crop_w;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (n >= a.cout) continue;
+      const float bias = a.bias ? a.bias[n] : 0.f;
+      const float inv = a.inv_scale[n];
+      const size_t base = ((size_t)img * a.cout + n) * plane;
+#pragma unroll
+      for (int mr = 0; mr < MREP; ++mr) {
+        const int oy = oy0 + wave * MREP + mr;
+        if (oy < a.crop_h && px < a.crop_w) {
+          const size_t o = base + (size_t)oy * a.crop_w + px;
+          float v = acc[mr][0][r] * inv + bias;
+          if (a.nchw_op == VIRNET_NCHW_ADD) {
+            if (a.res_sf > 1) {
+              const int rw = a.crop_w / a.res_sf;
+              v += a.res[((size_t)img * a.cout + n) * (size_t)(a.crop_h / a.res_sf) * rw + (size_t)(oy / a.res_sf) * rw + px / a.res_sf];
+            } else {
+              v += a.res[o];
+            }
+          } else if (a.nchw_op == VIRNET_NCHW_EXPCLAMP) {
+            v = expf(fminf(fmaxf(v, a.clamp_lo), a.clamp_hi));
+          }
+          a.y_raw[o] = v;
+        }
+      }
+    }
+    TSTAMP(3);
+    return;
+  }
   // Each wave turns its own MREP x 32 pixel x 32 channel slab around through a private LDS region ([pixel][32 channels], 16 B of
   // padding per pixel; the pixel / weight buffers are free after the last barrier): lane = (pixel j>>3 of 8, channel quad j&7), so
   // one store / residual-load instruction covers 8 pixels x 128 contiguous bytes instead of 32 scattered 32-B pieces.
@@ -533,11 +566,21 @@ extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int c
 extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
-  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_f16: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
-                 d->ks, d->stride, d->epi);
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW),
+                 "virnet_conv_f16: only the stride-1 3x3 conv with NHWC or planar store (ks=%d stride=%d epi=%d)", d->ks, d->stride, d->epi);
   VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_f16: empty input n=%d h=%d w=%d", d->n, d->h, d->w);
   VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_f16: cin_pad=%d is not a multiple of 16", d->cin_pad);
-  VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_f16: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
+  if (d->epi == VIRNET_EPI_NCHW) {
+    VIRNET_REQUIRE(d->cout >= 1 && d->cout <= 32 && d->n_pad == 32, "virnet_conv_f16: planar store handles 1..32 channels (cout=%d n_pad=%d)", d->cout, d->n_pad);
+    VIRNET_REQUIRE(d->y_raw && !d->y_act && !d->mask && !d->mul, "virnet_conv_f16: planar store takes y_raw only");
+    VIRNET_REQUIRE(d->crop_h >= 1 && d->crop_h <= d->h && d->crop_w >= 1 && d->crop_w <= d->w, "virnet_conv_f16: crop %dx%d outside output %dx%d",
+                   d->crop_h, d->crop_w, d->h, d->w);
+    VIRNET_REQUIRE(d->nchw_op != VIRNET_NCHW_ADD || d->res, "virnet_conv_f16: VIRNET_NCHW_ADD without res");
+    VIRNET_REQUIRE(d->res_sf <= 1 || (d->crop_h % d->res_sf == 0 && d->crop_w % d->res_sf == 0), "virnet_conv_f16: crop %dx%d is not a multiple of res_sf=%d",
+                   d->crop_h, d->crop_w, d->res_sf);
+  } else {
+    VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_f16: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
+  }
   VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_f16: no output pointer");
   VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_f16: in_mul and in_add must be given together");
   VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_f16: in_mul/in_add without in_act");
@@ -549,18 +592,19 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   k.in_mul = d->in_mul; k.in_add = d->in_add; k.mask = d->mask; k.y_raw = d->y_raw; k.y_act = d->y_act;
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.NP = d->n_pad; k.cout = d->cout;
   k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
+  k.nchw_op = d->nchw_op; k.crop_h = d->crop_h; k.crop_w = d->crop_w; k.res_sf = d->res_sf; k.clamp_lo = d->clamp_lo; k.clamp_hi = d->clamp_hi;
 #ifdef VIRNET_F16_TIMING
   k.tlog = g_tlog;
 #endif
-  { const char* const env_s = getenv("VIRNET_F16_STAGGER"); k.stagger = env_s ? atoi(env_s) : 0; }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nb = d->cout / 32;
+  const int nb = d->n_pad / 32;
   const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
   const char* const env_m = getenv("VIRNET_F16_MREP");      // tuning / tests (read per call)
   const int forced_m = env_m ? atoi(env_m) : 0;
   const int nrep = (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
   int mrep = (tiles8 * (nb / nrep) >= 1024) ? 2 : 1;
   if (forced_m == 1 || forced_m == 2) mrep = forced_m;
+  if (d->epi == VIRNET_EPI_NCHW) return mrep == 2 ? launch<2, 1, 5>(k, st) : launch<1, 1, 5>(k, st);
   const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
 #define VIRNET_F16_CASE(M_, N_)                       \
   if (mrep == M_ && nrep == N_) {                     \

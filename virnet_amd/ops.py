@@ -111,11 +111,10 @@ def pack_f16_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
     if (kh, kw) != (3, 3):
         raise ValueError("the split-fp16 form is for 3x3 kernels")
     rows, ks = (cin, cout) if dgrad else (cout, cin)
-    if rows % 32:
-        raise ValueError(f"the split-fp16 kernel stores multiples of 32 channels, got {rows}")
+    n_pad = (rows + 31) // 32 * 32            # (rows beyond the real ones are zero; the planar store keeps the real channels)
     cin_pad = (ks + 15) // 16 * 16
-    out = torch.empty(lib.virnet_f16_weight_floats(cin_pad, rows), dtype=torch.float32, device=weight.device)
-    nat.check(lib.virnet_pack_f16_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, rows, nat.ptr(out), nat.stream_handle()),
+    out = torch.empty(lib.virnet_f16_weight_floats(cin_pad, n_pad), dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_f16_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, n_pad, nat.ptr(out), nat.stream_handle()),
               "pack_f16_weight")
     return out
 
@@ -206,10 +205,12 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         b = bias.detach()
         _dev_check(b, "bias")
     pw = PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
-    if kind == 0 and ks == 3 and stride == 1 and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
-        if conv_form() == "wino":
+    if kind == 0 and ks == 3 and stride == 1:
+        if conv_form() == "wino" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
             pw.wino = pack_wino_weight(weight)
-        elif conv_form() == "f16x3":
+        elif conv_form() == "f16x3" and (cout % 32 == 0 or cout <= 32):
+            # every stride-1 3x3 layer: the C->C convs, the few-input-channel entry convs (HBM-bound: one 16-channel chunk) and, through
+            # the planar store, the few-output-channel exits
             pw.f16 = pack_f16_weight(weight)
     return pw
 
@@ -250,7 +251,7 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         want = conv_form()
         if want == "wino" and pw.wino is not None:
             form = "wino"
-        elif want == "f16x3" and pw.f16 is not None:
+        elif want == "f16x3" and pw.f16 is not None and pw.cout % 32 == 0:
             form = "f16x3"
     wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16}[form]
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
@@ -284,6 +285,36 @@ def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op:
                      nrep=pw.nrep, ks=pw.ks, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
                      res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
     _launch_conv(d, 2.0 * n * h * w * pw.cin_real * pw.cout * pw.ks ** 2, "conv_mfma(nchw)")
+    return out
+
+
+def conv_f16_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: int = nat.NCHW_PLAIN,
+                  res: Optional[Tensor] = None, res_sf: int = 1, clamp: Tuple[float, float] = (0.0, 0.0)) -> Tensor:
+    """Few-output-channel (<= 32) 3x3 conv on the split-fp16 kernel with planar (NCHW) store, crop and fused `+res` / `exp(clamp(.))`."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    if pw.f16 is None or c != pw.cin_pad or pw.cout > 32:
+        raise ValueError(f"x has {c} channels / weight has no split-fp16 image for a planar store (cin_pad {pw.cin_pad}, cout {pw.cout})")
+    ch, cw = crop_hw
+    out = torch.empty((n, pw.cout, ch, cw), dtype=torch.float32, device=x.device)
+    if res is not None:
+        _dev_check(res, "res")
+        if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
+            raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0, mask=0,
+                     mask_slope=0.0, in_mul=0, in_add=0, in_act=0, in_slope=0.0, y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout,
+                     n_pad=32, nrep=1, ks=3, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
+                     res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
+    flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 9
+    lib = nat.load()
+    if _TIMER is None:
+        nat.check(lib.virnet_conv_f16(C.byref(d), nat.stream_handle()), "conv_f16(nchw)")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.check(lib.virnet_conv_f16(C.byref(d), nat.stream_handle()), "conv_f16(nchw)")
+        e1.record()
+        _TIMER.records.append((("f16x3", pw.cout), flops, e0, e1))
     return out
 
 
