@@ -36,6 +36,7 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 // -DVIRNET_F16_TIMING: wave 0 of every workgroup logs s_memtime at start / after the prologue / after the K loop / at exit plus
@@ -200,18 +201,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.f;
 
-  // ---- prologue: weights of stage 0 by DMA, pixels of chunk 0 staged whole, chunk 1's first pieces requested by group 0
+  // ---- prologue: weights of stage 0 by DMA, pixels of chunk 0 staged whole; chunk 1's pieces are requested by the groups of chunk 0
   dma_group(0, w_lds);
-  {
-    f32x4 r0[PPT], r1[PPT];
+  f32x4 pr0[PPT], pr1[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-      r0[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k]);
-      r1[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k] + 4);
-    }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) stage_store(x_lds, 0, k, r0[k], r1[k]);
+  for (int k = 0; k < PPT; ++k) {
+    pr0[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k]);
+    pr1[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k] + 4);
   }
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) stage_store(x_lds, 0, k, pr0[k], pr1[k]);
   __syncthreads();
   TSTAMP(1);
 
@@ -357,7 +356,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
   constexpr int TPIX = 144, NIT = MREP * 4;          // 8 pixels per pass
-  char* const tbuf = smem + wave * (MREP * 32 * TPIX);
+  constexpr int TREG = MREP * 32 * TPIX;             // one slab of one wave; two regions per wave (ping-pong)
+  static_assert(4 * 2 * TREG <= 81920, "turn-around regions: two workgroups per CU");   // (launch<> sizes LDS for the larger of the two)
+  char* const tbuf = smem + wave * (2 * TREG);
   const int cq = lane & 7, psub = lane >> 3;
   unsigned eoff[NIT];
   bool eok[NIT];
@@ -368,12 +369,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     eok[it] = oy < a.H && ox < a.W;
     eoff[it] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)(nbase + cq * 4);
   }
-  auto turn_in = [&](int nr) {
+  auto turn_in = [&](int nr, int region = 0) {
 #pragma unroll
     for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(tbuf + (mr * 32 + l31) * TPIX + (8 * g + 4 * lhi) * 4) =
+        *reinterpret_cast<f32x4*>(tbuf + region * TREG + (mr * 32 + l31) * TPIX + (8 * g + 4 * lhi) * 4) =
             f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
   };
   auto mask4 = [&](f32x4 v, f32x4 m) {
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       }
     }
     TSTAMP(6);
-    turn_in(0);
+    turn_in(0, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
@@ -417,6 +418,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       }
     }
 #endif
+    // stores through a buffer descriptor: out-of-image lanes get an out-of-range offset and are dropped by the bounds check, so the
+    // slab loop has no branch (the tile's reads, arithmetic and stores stay one schedulable block)
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
+    unsigned yoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) yoff[it] = eok[it] ? eoff[it] * 4u : 0x80000000u;
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       f32x4 mv[NIT], rv[NIT];
@@ -427,14 +434,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
           rv[it] = *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
         }
       }
-      if (nr > 0) turn_in(nr);
+      if (nr + 1 < NREP) turn_in(nr + 1, (nr + 1) & 1);          // next slab into the other region while this one is read back
       const f32x4 b4 = bias4[nr] * hb;
+      f32x4 tv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) tv[it] = *reinterpret_cast<const f32x4*>(tbuf + (nr & 1) * TREG + (it * 8 + psub) * TPIX + cq * 16);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + (it * 8 + psub) * TPIX + cq * 16) * inv4[nr] + b4;
+        f32x4 v = tv[it] * inv4[nr] + b4;
         if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[HOIST ? nr : 0][it]);
         if (RES) v += EPI == 3 ? rv[it] : op1[HOIST ? nr : 0][it];
-        if (eok[it]) *reinterpret_cast<f32x4*>(y + eoff[it] + nr * 32) = lrelu4(v, slope_eff);
+        v = lrelu4(v, slope_eff);
+        // (the slab offset rides in the instruction's immediate, NOT in soffset: hipcc 7.2 schedules a v_pk_* write of the data
+        // registers straight behind a 16-B buffer store with an SGPR offset -- the hazard that needs a wait state -- and the odd
+        // elements of the stored quad come out wrong)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
       }
       if (nr == 0) TSTAMP(7);
     }
@@ -485,7 +499,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 template <int MREP, int NREP, int EPI>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
-  constexpr int LDS = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);
+  constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);       // K loop: pixel tiles + weight stages
+  constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144);                  // epilogue: two turn-around regions per wave
+  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static unsigned long long attr_done = 0;
   auto kern = conv_f16_kernel<MREP, NREP, EPI>;
   if (virnet::first_use_on_device(attr_done)) {
@@ -582,6 +598,7 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
     VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_f16: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
   }
   VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_f16: no output pointer");
+  VIRNET_REQUIRE((long)d->h * d->w * d->n_pad * 4 < (1L << 31), "virnet_conv_f16: one image's output (%d x %d x %d fp32) must stay below 2 GB", d->h, d->w, d->n_pad);
   VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_f16: in_mul and in_add must be given together");
   VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_f16: in_mul/in_add without in_act");
   VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_f16: in_slope=%g outside [0,1]", d->in_slope);
