@@ -206,3 +206,29 @@ def denoise_table(forward, data: Sequence[str], noise_type: str = "niid", rng: "
                          "psnr": float(np.mean(psnrs)), "ssim": float(np.mean(ssims)) if ssims else float("nan"),
                          "images": len(files), "per_image_psnr": psnrs})
     return rows
+
+
+# ---- 8-way flip/rotation self-ensemble (scripts/denoising_virnet_real_sidd.py:120-136, utils/util_image.py:391-436) ------------------
+def dihedral(im: np.ndarray, mode: int) -> np.ndarray:
+    """Element ``mode`` of the square's symmetry group on an [h,w,c] image: k = mode//2 quarter turns counter-clockwise, then an
+    up-down flip for odd modes (the reference's enumeration: 0 identity, 1 flip, 2 rot90, 3 rot90+flip, ...)."""
+    if not 0 <= mode < 8:
+        raise ValueError(f"mode {mode}: expected 0..7")
+    out = np.rot90(im, k=mode // 2)
+    return np.ascontiguousarray(np.flipud(out) if mode & 1 else out)
+
+
+def dihedral_inverse(im: np.ndarray, mode: int) -> np.ndarray:
+    """Undo :func:`dihedral`: flip back first, then turn back."""
+    if not 0 <= mode < 8:
+        raise ValueError(f"mode {mode}: expected 0..7")
+    out = np.flipud(im) if mode & 1 else im
+    return np.ascontiguousarray(np.rot90(out, k=-(mode // 2)))
+
+
+def flip_ensemble(forward, noisy: np.ndarray) -> np.ndarray:
+    """Mean of the eight back-transformed restorations of the eight transformed inputs (``--flip`` of the SIDD / DND scripts)."""
+    acc = np.zeros(noisy.shape, dtype=np.float32)
+    for mode in range(8):
+        acc += dihedral_inverse(np.asarray(forward(dihedral(noisy, mode)), dtype=np.float32), mode)
+    return acc / 8

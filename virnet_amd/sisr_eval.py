@@ -105,3 +105,33 @@ def degrade(im_hr: np.ndarray, kernel: np.ndarray, sf: int, nlevel: float = 2.55
         raise ValueError("downsampler must be 'direct' or 'bicubic'")
     lr = lr + np.random.default_rng(seed).standard_normal(size=lr.shape) * (nlevel / 255.0)
     return np.clip(lr.astype(np.float32), 0.0, 1.0)
+
+
+def sisr_table(forward, data, sf: int, nlevel: float = 2.55, kernels=None, with_ssim: bool = True):
+    """The PSNR-Y / SSIM-Y table of scripts/sisr_virnet_syn.py:99-170 for any ``forward(lr float32 HWC, sf) -> sr float32 HWC``:
+    per dataset and per test kernel (seven, :103-116), every ground-truth image is mod-cropped, blurred, bicubically downscaled,
+    noised with the seeded stream (util_sisr.py:146-177) and restored; metrics on the uint8 Y channel with border sf**2 (:150).
+    LPIPS needs the pretrained AlexNet of the `lpips` package and is outside this path.  ``data`` = ["folder:ext", ...].
+    Returns rows {"dataset", "kernel", "psnr_y", "ssim_y", "images", "per_image_psnr_y"}."""
+    import glob
+    import os
+    from . import eval as veval
+    kernels = test_kernels(sf) if kernels is None else kernels
+    rows = []
+    for spec in data:
+        folder, ext = spec.rsplit(":", 1)
+        files = sorted(glob.glob(os.path.join(folder, "*." + ext.lstrip("."))))
+        if not files:
+            continue
+        for kidx, kernel in enumerate(kernels):
+            psnrs, ssims = [], []
+            for f in files:
+                gt = modcrop(veval.imread_rgb_uint8(f), sf)
+                lr = degrade(veval.img_as_float32(gt), kernel, sf, nlevel=nlevel, downsampler="bicubic")
+                sr = veval.img_as_ubyte(np.clip(forward(lr, sf), 0.0, 1.0))
+                psnrs.append(veval.calculate_psnr_y(sr, gt, border=sf ** 2))
+                if with_ssim:
+                    ssims.append(veval.calculate_ssim(sr, gt, border=sf ** 2, ycbcr=True))
+            rows.append({"dataset": os.path.basename(folder.rstrip("/")), "kernel": kidx + 1, "psnr_y": float(np.mean(psnrs)),
+                         "ssim_y": float(np.mean(ssims)) if ssims else float("nan"), "images": len(files), "per_image_psnr_y": psnrs})
+    return rows
