@@ -216,6 +216,9 @@ int virnet_pack_input_backward(const float* drec, int crec, int chan, const floa
 /* KernelNet.head: Conv2d(cin -> cout, k=9, s=4, p=4, bias=False) (KNet.py:45,53).  x NCHW [n][cin][h][w], w OIHW,
  * out NHWC [n][oh][ow][cout] with oh = (h-1)/4+1, ow = (w-1)/4+1; cout a multiple of 64. */
 int virnet_conv_head_s4(const float* x, const float* w, float* out, int n, int cin, int h, int w_, int cout, void* stream);
+/* Its weight gradient (SISR training step, train_SISR.py:207-224): dw[cout][cin][9][9] = sum_{n,oy,ox} dy[n][oy][ox][co] *
+ * x[n][ci][4oy+ky-4][4ox+kx-4]; x NCHW, dy NHWC [n][oh][ow][cout]; dw is overwritten. */
+int virnet_conv_head_s4_wgrad(const float* x, const float* dy, float* dw, int n, int cin, int h, int w_, int cout, void* stream);
 
 /* Global average pool of a planar tensor [n][c][h][w] -> out[n][c], with the finishing op of its call site:
  *   VIRNET_GAP_MEAN      mean                                  (DnCNN.py:31,42)

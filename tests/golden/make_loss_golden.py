@@ -32,3 +32,35 @@ json.dump(dict(seed=[77, 1], shape=list(shape), eps2=1e-6, var_window=7, values=
                dsigma_sum=float(sigma.grad.double().sum()), dsigma_absmax=float(sigma.grad.abs().max())),
           open(os.path.join(HERE, "loss.json"), "w"), indent=1)
 print([float(v) for v in out])
+
+
+# ---- elbo_sisr (loss/ELBO_simple.py:82-138) as train_SISR.py:207-224 calls it; the three random draws come from torch's seeded
+# global generator, so the restatement must draw in the same order to reproduce these values
+from loss.ELBO_simple import elbo_sisr  # noqa: E402  (the reference)
+
+out_sisr = {}
+for down in ("Bicubic", "Direct"):
+    g = np.random.Generator(np.random.Philox(key=[78, 2]))
+    n, sf, hl, wl = 2, 2, 9, 11
+    mu = torch.from_numpy(g.random((n, 3, hl * sf, wl * sf), dtype=np.float32)).requires_grad_(True)
+    sigma = torch.from_numpy(g.random((n, 1, 1, 1), dtype=np.float32) * 0.01 + 1e-4).requires_grad_(True)
+    kinfo = torch.from_numpy(np.stack([g.random(n) * 3 + 0.5, g.random(n) * 3 + 0.5, g.random(n) * 1.2 - 0.6], 1).astype(np.float32)).requires_grad_(True)
+    im_hr = torch.from_numpy(g.random((n, 3, hl * sf, wl * sf), dtype=np.float32))
+    im_lr = torch.from_numpy(g.random((n, 3, hl, wl), dtype=np.float32))
+    prior = torch.from_numpy(g.random((n, 1, 1, 1), dtype=np.float32) * 0.01 + 1e-4)
+    kgt = torch.from_numpy(np.stack([g.random(n) * 3 + 0.5, g.random(n) * 3 + 0.5, g.random(n) * 1.2 - 0.6], 1).astype(np.float32))
+    alpha0 = 0.5 * torch.tensor([9 ** 2], dtype=torch.float32)
+    kappa0 = torch.tensor([50.0])
+    torch.manual_seed(4321)
+    loss, det = elbo_sisr(mu=mu, sigma_est=sigma, kinfo_est=kinfo, im_hr=im_hr, im_lr=im_lr, sigma_prior=prior, alpha0=alpha0,
+                          kinfo_gt=kgt, kappa0=kappa0, r2=1e-4, eps2=1e-5, sf=sf, k_size=9, penalty_K=[0.02, 2], shift=False,
+                          downsampler=down)
+    loss.backward()
+    out_sisr[down] = dict(values=[float(loss)] + [float(v) for v in det[:7]], kernel_sum=float(det[7].double().sum()),
+                          kernel_max=float(det[7].max()), kernel_00=[float(det[7][0, 0, 4, 4]), float(det[7][1, 0, 3, 5])],
+                          dmu_sum=float(mu.grad.double().sum()), dmu_absmax=float(mu.grad.abs().max()),
+                          dsigma=[float(v) for v in sigma.grad.reshape(-1)], dkinfo=[float(v) for v in kinfo.grad.reshape(-1)])
+json.dump(dict(seed=[78, 2], torch_seed=4321, n=2, sf=2, lr_hw=[9, 11], k_size=9, var_window=9, kappa0=50.0, r2=1e-4, eps2=1e-5,
+               penalty_K=[0.02, 2], cases=out_sisr, torch_version=torch.__version__),
+          open(os.path.join(HERE, "loss_sisr.json"), "w"), indent=1)
+print({k: v["values"][:3] for k, v in out_sisr.items()})

@@ -249,6 +249,3 @@ def test_optimizer_step_and_repack():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
-    with pytest.raises(NotImplementedError):
-        from virnet_amd.networks import VIRAttResUNetSR
-        VIRAttResUNetSR(3, n_feat=[64, 96]).cuda()(x, 2)

@@ -28,3 +28,38 @@ def test_elbo_matches_reference():
     assert float(mu.grad.abs().max()) == pytest.approx(ref["dmu_absmax"], rel=1e-6)
     assert float(sigma.grad.double().sum()) == pytest.approx(ref["dsigma_sum"], rel=1e-5)
     assert float(sigma.grad.abs().max()) == pytest.approx(ref["dsigma_absmax"], rel=1e-6)
+
+
+@pytest.mark.parametrize("down", ["Bicubic", "Direct"])
+def test_elbo_sisr_matches_reference_golden(down):
+    """virnet_amd.loss.elbo_sisr against the reference's loss/ELBO_simple.py::elbo_sisr (tests/golden/loss_sisr.json, produced by
+    make_loss_golden.py from the reference itself): same seeded inputs, same torch generator seed -- the restatement must consume the
+    random draws in the reference's order (Gamma rsample, randn for rho, randn_like(mu)) -- values, sampled kernel and all gradients."""
+    from virnet_amd.loss import elbo_sisr
+    G = json.load(open(os.path.join(GOLDEN, "loss_sisr.json")))
+    if G["torch_version"] != torch.__version__:
+        pytest.skip(f"golden drawn with torch {G['torch_version']}, this is {torch.__version__}: the random streams may differ")
+    c = G["cases"][down]
+    g = np.random.Generator(np.random.Philox(key=G["seed"]))
+    n, sf, (hl, wl) = G["n"], G["sf"], G["lr_hw"]
+    mu = torch.from_numpy(g.random((n, 3, hl * sf, wl * sf), dtype=np.float32)).requires_grad_(True)
+    sigma = torch.from_numpy(g.random((n, 1, 1, 1), dtype=np.float32) * 0.01 + 1e-4).requires_grad_(True)
+    kinfo = torch.from_numpy(np.stack([g.random(n) * 3 + 0.5, g.random(n) * 3 + 0.5, g.random(n) * 1.2 - 0.6], 1).astype(np.float32)).requires_grad_(True)
+    im_hr = torch.from_numpy(g.random((n, 3, hl * sf, wl * sf), dtype=np.float32))
+    im_lr = torch.from_numpy(g.random((n, 3, hl, wl), dtype=np.float32))
+    prior = torch.from_numpy(g.random((n, 1, 1, 1), dtype=np.float32) * 0.01 + 1e-4)
+    kgt = torch.from_numpy(np.stack([g.random(n) * 3 + 0.5, g.random(n) * 3 + 0.5, g.random(n) * 1.2 - 0.6], 1).astype(np.float32))
+    alpha0 = 0.5 * torch.tensor([G["var_window"] ** 2], dtype=torch.float32)
+    kappa0 = torch.tensor([G["kappa0"]])
+    torch.manual_seed(G["torch_seed"])
+    loss, det = elbo_sisr(mu=mu, sigma_est=sigma, kinfo_est=kinfo, im_hr=im_hr, im_lr=im_lr, sigma_prior=prior, alpha0=alpha0,
+                          kinfo_gt=kgt, kappa0=kappa0, r2=G["r2"], eps2=G["eps2"], sf=sf, k_size=G["k_size"], penalty_K=G["penalty_K"],
+                          shift=False, downsampler=down)
+    loss.backward()
+    got = [float(loss)] + [float(v) for v in det[:7]]
+    assert got == pytest.approx(c["values"], rel=2e-5)
+    assert float(det[7].double().sum()) == pytest.approx(c["kernel_sum"], rel=1e-6) and float(det[7].max()) == pytest.approx(c["kernel_max"], rel=1e-5)
+    assert [float(det[7][0, 0, 4, 4]), float(det[7][1, 0, 3, 5])] == pytest.approx(c["kernel_00"], rel=1e-5)
+    assert float(mu.grad.double().sum()) == pytest.approx(c["dmu_sum"], rel=1e-4) and float(mu.grad.abs().max()) == pytest.approx(c["dmu_absmax"], rel=1e-4)
+    assert [float(v) for v in sigma.grad.reshape(-1)] == pytest.approx(c["dsigma"], rel=1e-4)
+    assert [float(v) for v in kinfo.grad.reshape(-1)] == pytest.approx(c["dkinfo"], rel=2e-3, abs=1e-4)

@@ -15,7 +15,7 @@ BENCH="python $ROOT/bench.py --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH --steps 5 --warmup 2 > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE \
   --kernel-trace -d "$OUT/pmc_sq" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_sq.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_INSTS_SALU \
+rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU \
   --kernel-trace -d "$OUT/pmc_sq2" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_write.log" 2>&1

@@ -13,6 +13,9 @@ def short(name):
     m = re.search(r"conv_mfma_kernel<([^>]*)>", name)
     if m:
         return "conv_mfma_kernel<%s>" % m.group(1).replace("(anonymous namespace)::", "").replace(" ", "")
+    m = re.search(r"(conv_f16_kernel)<([^>]*)>", name)
+    if m:
+        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     m = re.search(r"(conv_wino\w*_kernel)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))

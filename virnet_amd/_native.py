@@ -105,6 +105,8 @@ SYMBOLS = [
                                              C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_conv_head_s4", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]),
+    ("virnet_conv_head_s4_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p]),
     ("virnet_gap_nchw", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_float, C.c_void_p]),
     ("virnet_ca_gate", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

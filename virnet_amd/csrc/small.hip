@@ -47,6 +47,30 @@ __global__ __launch_bounds__(256) void conv_head_s4_kernel(const float* __restri
   }
 }
 
+// Weight gradient of the same layer (SISR training step, train_SISR.py:207-224): dw[co][ci][ky][kx] = sum over images and output
+// pixels of dy[n][oy][ox][co] * x[n][ci][4oy+ky-4][4ox+kx-4].  One block per (ci, ky, kx), one thread per output channel: the input
+// sample is a wave-uniform broadcast, dy is read channel-contiguous.  0.17 % of the SISR FLOPs: latency class, not tuned.
+__global__ __launch_bounds__(64) void conv_head_s4_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 float* __restrict__ dw, int n, int cin, int h, int wd, int cout,
+                                                                 int oh, int ow) {
+  const int kx = blockIdx.x % 9, ky = (blockIdx.x / 9) % 9, ci = blockIdx.x / 81;
+  for (int co = threadIdx.x; co < cout; co += 64) {
+    float acc = 0.f;
+    for (int img = 0; img < n; ++img) {
+      const float* xp = x + ((size_t)img * cin + ci) * h * wd;
+      for (int oy = 0; oy < oh; ++oy) {
+        const int iy = oy * 4 - 4 + ky;
+        if ((unsigned)iy >= (unsigned)h) continue;
+        for (int ox = 0; ox < ow; ++ox) {
+          const int ix = ox * 4 - 4 + kx;
+          if ((unsigned)ix < (unsigned)wd) acc = fmaf(dy[(((size_t)img * oh + oy) * ow + ox) * cout + co], xp[(size_t)iy * wd + ix], acc);
+        }
+      }
+    }
+    dw[(((size_t)co * cin + ci) * 9 + ky) * 9 + kx] = acc;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // block-wide sum of one float per thread (256 threads): wave64 shuffles, then 4 partials through LDS.
 // ----------------------------------------------------------------------------------------------------------------
@@ -244,6 +268,16 @@ extern "C" int virnet_conv_head_s4(const float* x, const float* w, float* out, i
   hipLaunchKernelGGL(conv_head_s4_kernel, dim3(gx, cout / 64), dim3(256), lds, static_cast<hipStream_t>(stream), x, w, out, n,
                      cin, h, w_, cout, oh, ow, ppb);
   return virnet::check_launch("conv_head_s4 launch");
+}
+
+extern "C" int virnet_conv_head_s4_wgrad(const float* x, const float* dy, float* dw, int n, int cin, int h, int w_, int cout,
+                                         void* stream) {
+  VIRNET_REQUIRE(x && dy && dw, "virnet_conv_head_s4_wgrad: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && h > 0 && w_ > 0 && cin > 0 && cout > 0, "virnet_conv_head_s4_wgrad: bad shape");
+  const int oh = (h - 1) / 4 + 1, ow = (w_ - 1) / 4 + 1;
+  hipLaunchKernelGGL(conv_head_s4_wgrad_kernel, dim3(cin * 81), dim3(64), 0, static_cast<hipStream_t>(stream), x, dy, dw, n, cin, h,
+                     w_, cout, oh, ow);
+  return virnet::check_launch("conv_head_s4_wgrad launch");
 }
 
 extern "C" int virnet_gap_nchw(const float* x, float* out, int n, int c, int h, int w, int finish, float lo, float hi,

@@ -63,10 +63,13 @@ class VIRAttResUNetSR(nn.Module):
                                extra_mode=extra_mode)
 
     def forward(self, x: torch.Tensor, sf: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """x [N,C,h,w], sf -> (mu [N,C,h*sf,w*sf], kinfo [N,kernel_chn], sigma) (VIRNet.py:80-97).  Inference only so far."""
+        """x [N,C,h,w], sf -> (mu [N,C,h*sf,w*sf], kinfo [N,kernel_chn], sigma) (VIRNet.py:80-97).
+
+        With gradients enabled and trainable parameters the call is recorded for ``loss.backward()`` (train_SISR.py:207-224): every
+        convolution's forward and backward run on the HIP kernels (virnet_amd/train_sisr.py)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("VIRAttResUNetSR: the training step (KNet / SFT backward) is not built on the HIP path yet; "
-                                      "call it under torch.no_grad() for inference")
+            from .. import train_sisr
+            return train_sisr.sisr_forward_train(self, x, sf)
         return engine.sisr_forward(self, x, sf)
 
     def graphed(self) -> GraphedForward:

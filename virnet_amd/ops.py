@@ -410,6 +410,19 @@ def conv_head_s4(x: Tensor, weight: Tensor) -> Tensor:
     return out
 
 
+def conv_head_s4_wgrad(x: Tensor, dy: Tensor, cout: int) -> Tensor:
+    """Weight gradient [cout, cin, 9, 9] of KernelNet.head from the NCHW input and the NHWC output gradient."""
+    _dev_check(x, "x"); _dev_check(dy, "dy")
+    n, cin, h, w = x.shape
+    oh, ow = (h - 1) // 4 + 1, (w - 1) // 4 + 1
+    if tuple(dy.shape) != (n, oh, ow, cout):
+        raise ValueError(f"dy shape {tuple(dy.shape)} != {(n, oh, ow, cout)}")
+    dw = torch.empty((cout, cin, 9, 9), dtype=torch.float32, device=x.device)
+    nat.check(nat.load().virnet_conv_head_s4_wgrad(nat.ptr(x), nat.ptr(dy), nat.ptr(dw), n, cin, h, w, cout, nat.stream_handle()),
+              "conv_head_s4_wgrad")
+    return dw
+
+
 def ca_gate(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
     """CALayer gate [N,C] from NHWC features."""
     _dev_check(x, "x")

@@ -1,0 +1,254 @@
+"""Training step of the super-resolution model on the HIP path (reference train_SISR.py:207-224).
+
+``VIRAttResUNetSR.forward`` routes here when gradients are enabled.  Every convolution -- forward, input gradient and weight gradient
+-- runs on the C-ABI kernels through small ``torch.autograd.Function`` wrappers (the same kernels the denoiser's training step uses:
+``virnet_conv_mfma`` / ``virnet_conv_f16`` with the dgrad packings, ``virnet_conv_wgrad``, ``virnet_colsum``, plus
+``virnet_conv_head_s4`` / ``virnet_conv_head_s4_wgrad`` for KNet's 9x9 stride-4 entry).  What sits BETWEEN the convolutions in this
+model -- the SFT modulation ``lrelu(x*mul+add)`` with per-image vectors, the AttLayer / CALayer MLPs on [N, C] vectors, global average
+pools, ``exp(clamp)`` / ``tanh`` -- is expressed as PyTorch device ops on the NHWC tensors and differentiated by autograd: host-side
+tensor plumbing in BASELINE.json's sense, unfused for now (the inference path fuses all of it into the conv prologues / epilogues).
+So the numbers match the inference forward to fp32 noise, the step is complete (every one of the 225 parameters receives its gradient),
+and torch's DistributedDataParallel hooks fire layer by layer as the backward proceeds.
+
+Not built: per-pixel conditioning in training (``noise_avg=False``: SFT from maps, the JPEG variant of train_SISR.py:87).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _native as nat
+from . import ops
+from .engine import K_LOG_MIN, LOG_MAX, LOG_MIN, _ceil_to, _prep
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# convolutions: HIP forward / dgrad / wgrad behind autograd Functions (NHWC fp32 activations, reference-layout parameters)
+# ----------------------------------------------------------------------------------------------------------------------
+class _Conv3x3(torch.autograd.Function):
+    """3x3 conv, stride 1 or 2, NHWC -> NHWC (AttResBlock convs, DnCNN / RB_Layer convs, DownBlock.downsampler, entry convs)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, stride):
+        x = x.contiguous()
+        y, _ = ops.conv_mfma(x, conv.packed(), stride=stride, want_raw=True)
+        ctx.save_for_backward(x)
+        ctx.conv, ctx.stride = conv, stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        conv, stride = ctx.conv, ctx.stride
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if conv.cin < 16 and x.shape[-1] == 16:          # entry conv on 16-channel records: gradient of the whole record
+                dx = ops.conv_mfma(dy, conv.packed_dgrad(), want_raw=True, out_channels=32)[0][..., :16]
+            elif stride == 2:
+                dx = ops.conv_mfma(ops.zero_stuff2(dy), conv.packed_dgrad(), want_raw=True)[0]
+            else:
+                dx = ops.conv_mfma(dy, conv.packed_dgrad(), want_raw=True)[0]
+        dw = ops.conv_wgrad(x, dy, tuple(conv.weight.shape), stride=stride)
+        db = ops.colsum(dy) if conv.bias is not None else None
+        return dx, dw, db, None, None
+
+
+class _ConvT2x2(torch.autograd.Function):
+    """ConvTranspose2d(k=2, s=2) (UpBlock.upsampler, AttResUNet.py:80): 1x1 GEMM to 4*Cout + depth-to-space."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv):
+        x = x.contiguous()
+        y, _ = ops.conv_mfma(x, conv.packed(), want_raw=True)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        conv = ctx.conv
+        dy = dy.contiguous()
+        s2d = ops.space_to_depth2(dy)
+        dx = ops.conv_mfma(s2d, conv.packed_dgrad(), want_raw=True)[0] if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, s2d, tuple(conv.weight.shape), transposed=True)
+        return dx, dw, ops.colsum(dy), None
+
+
+class _ConvExit(torch.autograd.Function):
+    """3x3 conv to a few channels with planar store and crop (AttResUNet.tail, DnCNN.conv_last, KernelNet.tail): NHWC -> NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, crop_hw):
+        from .train import _thin
+        x = x.contiguous()
+        y = _thin(conv, x, crop_hw)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        conv = ctx.conv
+        n, hp, wp, _ = x.shape
+        g16 = ops.pack_input(dy.contiguous(), hp, wp, zero_pad=True)           # gradient records, zero beyond the crop
+        dx = ops.conv_mfma(g16, conv.packed_dgrad(), want_raw=True)[0] if ctx.needs_input_grad[0] else None
+        dw = ops.conv_wgrad(x, g16, tuple(conv.weight.shape))
+        db = ops.colsum(g16, conv.cout) if conv.bias is not None else None
+        return dx, dw, db, None, None
+
+
+class _HeadS4(torch.autograd.Function):
+    """KernelNet.head: 9x9 stride-4 conv without bias on the NCHW image (KNet.py:45,53); the image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x)
+        ctx.cout = weight.shape[0]
+        return ops.conv_head_s4(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return None, ops.conv_head_s4_wgrad(x, dy.contiguous(), ctx.cout)
+
+
+class _PackRecords(torch.autograd.Function):
+    """Entry records [N, hp, wp, 16] = [nearest-upsampled image | per-image vector repeated | 0] (VIRNet.py:83,89-92; util_net.py:20-25).
+    Only the vector is differentiable: every (padded) position reads the same value, so its gradient is the sum over positions."""
+
+    @staticmethod
+    def forward(ctx, x, vec, hp, wp, sf):
+        ctx.c0, ctx.ev = x.shape[1], vec.shape[1]
+        return ops.pack_input(x, hp, wp, sf=sf, vec=vec.contiguous())
+
+    @staticmethod
+    def backward(ctx, drec):
+        dvec = drec[..., ctx.c0:ctx.c0 + ctx.ev].sum(dim=(1, 2))
+        return None, dvec, None, None, None
+
+
+def _conv(x: Tensor, conv, stride: int = 1) -> Tensor:
+    return _Conv3x3.apply(x, conv.weight, conv.bias, conv, stride)
+
+
+def _lin(v: Tensor, conv) -> Tensor:
+    """1x1 conv on per-image vectors [N, C] (AttLayer, AttResUNet.py:18-25; CALayer body, KNet.py:17-19)."""
+    return F.linear(v, conv.weight.view(conv.cout, conv.cin), conv.bias)
+
+
+def _att_layer(vec: Tensor, att) -> Tuple[Tensor, Tensor]:
+    """AttLayer.forward on spatially constant conditioning (AttResUNet.py:27-32): (mul, add), each [N, nf]."""
+    f1 = F.leaky_relu(_lin(vec, att.conv1), 0.2)
+    f2 = F.leaky_relu(_lin(f1, att.conv2), 0.2)
+    return torch.sigmoid(_lin(f2, att.mul_conv)), _lin(f2, att.add_conv)
+
+
+def _res_block(x: Tensor, blk, vec: Optional[Tensor]) -> Tensor:
+    """AttResBlock.forward (AttResUNet.py:48-60) on NHWC tensors."""
+    if vec is not None and blk.extra_chn > 0:
+        mul1, add1 = _att_layer(vec, blk.sft1)
+        a1 = F.leaky_relu(x * mul1[:, None, None, :] + add1[:, None, None, :], 0.2)
+        f1 = _conv(a1, blk.conv1)
+        mul2, add2 = _att_layer(vec, blk.sft2)
+        a2 = F.leaky_relu(f1 * mul2[:, None, None, :] + add2[:, None, None, :], 0.2)
+    else:
+        f1 = _conv(F.leaky_relu(x, 0.2), blk.conv1)
+        a2 = F.leaky_relu(f1, 0.2)
+    return x + _conv(a2, blk.conv2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sub-networks
+# ----------------------------------------------------------------------------------------------------------------------
+def _snet(snet, x: Tensor) -> Tensor:
+    """DnCNN.forward (DnCNN.py:37-44) -> raw log-variance, [N,C,h,w] or pooled [N,C,1,1]."""
+    n, _, h, w = x.shape
+    cur = F.leaky_relu(_conv(ops.pack_input(x, h, w), snet.conv1), 0.25)
+    for key in sorted(snet.mid_layer.keys(), key=int):
+        cur = F.leaky_relu(_conv(cur, snet.mid_layer[key]), 0.25)
+    last = snet.conv_last
+    v = _ConvExit.apply(cur, last.weight, last.bias, last, (h, w))
+    return v.mean(dim=(2, 3), keepdim=True) if snet.noise_avg else v
+
+
+def _knet(knet, x: Tensor) -> Tensor:
+    """KernelNet.forward (KNet.py:52-59) -> [N, 3] = (lam1, lam2, rho)."""
+    k = _HeadS4.apply(x, knet.head.weight)
+    for rb in knet.body:
+        a = F.leaky_relu(_conv(k, rb.body["0"]), 0.2)                           # KNet.py:32-33
+        hcv = _conv(a, rb.body["2"])                                            # KNet.py:34
+        ca = rb.body["3"].body
+        y = F.leaky_relu(_lin(hcv.mean(dim=(1, 2)), ca["0"]), 0.2)              # KNet.py:15-19
+        gate = torch.sigmoid(_lin(y, ca["2"]))
+        k = hcv * gate[:, None, None, :] + k                                    # KNet.py:26,38
+    oh, ow = k.shape[1:3]
+    tail = knet.tail["0"]
+    m = _ConvExit.apply(k, tail.weight, tail.bias, tail, (oh, ow)).mean(dim=(2, 3))          # KNet.py:49-50
+    lam12 = torch.exp(torch.clamp(m[:, :-1], min=K_LOG_MIN, max=LOG_MAX))       # KNet.py:56
+    return torch.cat((lam12, torch.tanh(m[:, -1:])), dim=1)                     # KNet.py:57-58
+
+
+def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int) -> Tensor:
+    """AttResUNet.forward (AttResUNet.py:141-175) on the nearest-upsampled image with per-image conditioning vectors."""
+    n, _, h0, w0 = x_in.shape
+    H, W = h0 * sf, w0 * sf
+    m = 1 << (rnet.depth - 1)
+    hp, wp = _ceil_to(H, m), _ceil_to(W, m)
+    mode = rnet.extra_mode
+    feed_head, feed_down = mode in ("input", "both"), mode in ("down", "both")
+    if mode != "null" and (vec is None or vec.shape[1] != rnet.extra_chn):
+        raise ValueError(f"conditioning has {0 if vec is None else vec.shape[1]} channels, the network was built for {rnet.extra_chn}")
+    rec = _PackRecords.apply(x_in, vec, hp, wp, sf) if feed_head else ops.pack_input(x_in, hp, wp, sf=sf)
+    x = _conv(rec, rnet.head)                                                   # AttResUNet.py:153-155
+    cond = vec if feed_down else None
+    bridges: List[Tensor] = []
+    for ii, lvl in enumerate(rnet.down_path):
+        for blk in lvl.body:
+            x = _res_block(x, blk, cond)
+        if ii + 1 < len(rnet.down_path):
+            bridges.append(x)
+            x = _conv(x, lvl.downsampler, stride=2)                             # AttResUNet.py:67,74
+    for jj, up in enumerate(rnet.up_path):
+        us = up.upsampler
+        x = _ConvT2x2.apply(x, us.weight, us.bias, us) + bridges[-jj - 1]      # AttResUNet.py:84-87
+        for blk in up.body:
+            x = _res_block(x, blk, None)
+    tail = rnet.tail
+    out = _ConvExit.apply(x, tail.weight, tail.bias, tail, (H, W))             # AttResUNet.py:139,173 (crop)
+    x_up = x_in if sf == 1 else x_in.repeat_interleave(sf, dim=2).repeat_interleave(sf, dim=3)   # VIRNet.py:83 (nearest)
+    return out + x_up
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# boundary forward (networks/VIRNet.py:80-97) with gradients
+# ----------------------------------------------------------------------------------------------------------------------
+def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
+    if x.requires_grad:
+        raise RuntimeError("VIRAttResUNetSR: a gradient with respect to the input image is not implemented (train_SISR.py never asks "
+                           "for one); pass x.detach()")
+    if int(sf) != sf or sf < 1:
+        raise ValueError(f"sf must be a positive integer, got {sf}")
+    sf = int(sf)
+    x = _prep(x, net.SNet.in_channels)
+    n = x.shape[0]
+    if net.noise_cond and not net.noise_avg:
+        raise NotImplementedError("VIRAttResUNetSR training with a per-pixel variance map (noise_avg=False) is not built: the SFT layers "
+                                  "would need per-pixel modulation gradients; train with noise_avg=True (the reference's default)")
+    with torch.cuda.device(x.device):
+        sigma = torch.exp(torch.clamp(_snet(net.SNet, x), min=LOG_MIN, max=LOG_MAX))          # VIRNet.py:81
+        kinfo = _knet(net.KNet, x)                                                            # VIRNet.py:82
+        parts = []
+        if net.kernel_cond:
+            parts.append(kinfo)
+        if net.noise_cond:
+            parts.append(sigma.view(n, -1).sqrt())                                            # VIRNet.py:92
+        vec = torch.cat(parts, 1) if parts else None
+        mu = _rnet(net.RNet, x, vec, sf)
+    return mu, kinfo, sigma
