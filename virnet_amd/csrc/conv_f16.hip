@@ -61,7 +61,8 @@ struct FArgs {
   float* y_raw;
   float* y_act;
   int N, H, W, Cin;
-  int NP, cout;
+  int NP, cout;            // NP: GEMM rows (output channels) covered by THIS launch, starting at slab `slab_base`
+  int slab_base;
   int ntx, nty, ntiles, tiles_per_xcd;
   int in_act;
   int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 
   // ---- weight DMA: piece q = (tap-in-group, slab, hi|lo), 1 KB = the fragment of one MFMA operand; wave w moves pieces w, w+4, ...
   const size_t slab_bytes = (size_t)nch * 9 * 2048;
-  const char* const wcb = a.wimg + (size_t)(cb * NREP) * slab_bytes + lane * 16;
+  const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes + lane * 16;
   auto dma_group = [&](int stage, char* wb) {
 #pragma unroll
     for (int i = 0; i < (NDMA + 3) / 4; ++i) {
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   // Each wave turns its own MREP x 32 pixel x 32 channel slab around through a private LDS region ([pixel][32 channels], 16 B of
   // padding per pixel; the pixel / weight buffers are free after the last barrier): lane = (pixel j>>3 of 8, channel quad j&7), so
   // one store / residual-load instruction covers 8 pixels x 128 contiguous bytes instead of 32 scattered 32-B pieces.
-  const int nbase = cb * NB;
+  const int nbase = a.slab_base * 32 + cb * NB;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
@@ -618,21 +619,38 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
   const char* const env_m = getenv("VIRNET_F16_MREP");      // tuning / tests (read per call)
   const int forced_m = env_m ? atoi(env_m) : 0;
-  const int nrep = (nb % 3 == 0) ? 3 : (nb % 2 == 0) ? 2 : 1;
-  int mrep = (tiles8 * (nb / nrep) >= 1024) ? 2 : 1;
-  if (forced_m == 1 || forced_m == 2) mrep = forced_m;
-  if (d->epi == VIRNET_EPI_NCHW) return mrep == 2 ? launch<2, 1, 5>(k, st) : launch<1, 1, 5>(k, st);
-  const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
-#define VIRNET_F16_CASE(M_, N_)                       \
-  if (mrep == M_ && nrep == N_) {                     \
-    if (epi == 0) return launch<M_, N_, 0>(k, st);    \
-    if (epi == 1) return launch<M_, N_, 1>(k, st);    \
-    if (epi == 2) return launch<M_, N_, 2>(k, st);    \
-    if (epi == 3) return launch<M_, N_, 3>(k, st);    \
-    return launch<M_, N_, 4>(k, st);                  \
+  if (d->epi == VIRNET_EPI_NCHW) {
+    const int mrep = (forced_m == 1 || forced_m == 2) ? forced_m : (tiles8 >= 1024 ? 2 : 1);
+    k.slab_base = 0; k.NP = 32;
+    return mrep == 2 ? launch<2, 1, 5>(k, st) : launch<1, 1, 5>(k, st);
   }
-  VIRNET_F16_CASE(2, 3); VIRNET_F16_CASE(2, 2); VIRNET_F16_CASE(2, 1);
-  VIRNET_F16_CASE(1, 3); VIRNET_F16_CASE(1, 2); VIRNET_F16_CASE(1, 1);
+  const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
+  // Slabs per workgroup: 3 where the count allows, the remainder in 2s (160 channels = 3 + 2, 224 = 3 + 2 + 2: two launches, each
+  // staging the pixel tile once per workgroup, instead of 5 / 7 single-slab workgroups per tile); a lone odd slab runs by itself.
+  int n3 = nb / 3, rem = nb - 3 * n3;
+  if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
+  const int n2 = rem / 2, n1 = rem - 2 * n2;
+  auto run = [&](int nrep, int slab_base, int groups) -> int {
+    if (groups <= 0) return 0;
+    FArgs kk = k;
+    kk.slab_base = slab_base;
+    kk.NP = groups * nrep * 32;
+    int mrep = (tiles8 * groups >= 1024) ? 2 : 1;
+    if (forced_m == 1 || forced_m == 2) mrep = forced_m;
+#define VIRNET_F16_CASE(M_, N_)                        \
+    if (mrep == M_ && nrep == N_) {                    \
+      if (epi == 0) return launch<M_, N_, 0>(kk, st);  \
+      if (epi == 1) return launch<M_, N_, 1>(kk, st);  \
+      if (epi == 2) return launch<M_, N_, 2>(kk, st);  \
+      if (epi == 3) return launch<M_, N_, 3>(kk, st);  \
+      return launch<M_, N_, 4>(kk, st);                \
+    }
+    VIRNET_F16_CASE(2, 3) VIRNET_F16_CASE(2, 2) VIRNET_F16_CASE(2, 1)
+    VIRNET_F16_CASE(1, 3) VIRNET_F16_CASE(1, 2) VIRNET_F16_CASE(1, 1)
 #undef VIRNET_F16_CASE
-  return virnet::set_error("virnet_conv_f16: no kernel for mrep=%d nrep=%d", mrep, nrep);
+    return virnet::set_error("virnet_conv_f16: no kernel for mrep=%d nrep=%d", mrep, nrep);
+  };
+  if (int rc = run(3, 0, n3)) return rc;
+  if (int rc = run(2, 3 * n3, n2)) return rc;
+  return run(1, 3 * n3 + 2 * n2, n1);
 }
