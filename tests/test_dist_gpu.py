@@ -26,7 +26,7 @@ def _worker(rank, world, port, ret, own_reducer=False):
     if rank == 0:
         net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=4))
     if own_reducer:
-        ddp = vdist.DistributedTrainer(net, bucket_bytes=1 << 20)               # bucketed all-reduce overlapped with the backward kernels
+        ddp = vdist.DistributedTrainer(net, bucket_bytes=1 << 18)               # bucketed all-reduce overlapped with the backward kernels
     else:
         ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0])   # broadcasts rank 0's parameters (train_denoising_syn.py:71)
     opt = torch.optim.Adam(ddp.parameters(), lr=1e-3)
@@ -36,17 +36,36 @@ def _worker(rank, world, port, ret, own_reducer=False):
     x, gt = x_all[a:b].contiguous(), gt_all[a:b].contiguous()
     sig_gt = torch.full((b - a, 1, 16, 32), 0.01, device=dev)
     losses = []
+    # instrumentation: position of every all-reduce start relative to the weight-gradient launches of the same backward
+    from virnet_amd import ops as vops
+    events, real_ar, real_wgrad = [], dist.all_reduce, vops.conv_wgrad
+
+    def ar(*a, **k):
+        events.append("ar")
+        return real_ar(*a, **k)
+
+    def wg(*a, **k):
+        events.append("wgrad")
+        return real_wgrad(*a, **k)
+    early = []
     for _ in range(3):
         opt.zero_grad()
         mu, sigma = ddp(x)
         loss = elbo_denoising_simple(mu, sigma, x, gt, 1e-2, alpha0, alpha0 * sig_gt)[0]
-        loss.backward()                                                        # DDP all-reduces the HIP-computed gradients
+        events.clear()
+        dist.all_reduce, vops.conv_wgrad = ar, wg
+        try:
+            loss.backward()                                                    # DDP all-reduces the HIP-computed gradients
+        finally:
+            dist.all_reduce, vops.conv_wgrad = real_ar, real_wgrad
+        last_wgrad = max(i for i, e in enumerate(events) if e == "wgrad")
+        early.append(sum(1 for e in events[:last_wgrad] if e == "ar"))
         opt.step()
         losses.append(float(loss.detach()))
     flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
     gsum = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double().sum()
     ret[rank] = dict(psum=float(flat.double().sum()), gsum=float(gsum), losses=losses,
-                     buckets=ddp.reducer.bucket_sizes if own_reducer else None)
+                     buckets=ddp.reducer.bucket_sizes if own_reducer else None, early_allreduces=early)
     dist.destroy_process_group()
 
 
@@ -71,6 +90,10 @@ def test_distributed_trainer_matches_ddp():
         out.append(dict(ret[0]))
     ddp, own = out
     assert len(own["buckets"]) >= 2                                    # more than one collective per step
+    # overlap: in EVERY step (the first included) at least two buckets are already being reduced while weight-gradient kernels are
+    # still being launched; torch's DDP on the one-Function module reduces only after the whole backward
+    assert all(e >= 2 for e in own["early_allreduces"]), own["early_allreduces"]
+    assert all(e == 0 for e in ddp["early_allreduces"]), ddp["early_allreduces"]
     # (two runs of the same step differ by the summation order of the weight-gradient kernel's fp32 atomics; Adam's normalisation
     # amplifies that on near-zero gradients, so three steps later the losses agree to ~1e-5, not bit for bit)
     assert own["losses"] == pytest.approx(ddp["losses"], rel=1e-4), (own["losses"], ddp["losses"])

@@ -107,12 +107,13 @@ class GradientReducer:
         self._remaining: List[int] = []
         self._members: List[int] = []
         self._works: list = []
-        self._first: Dict[int, torch.Tensor] = {}
+        self._observing = True                              # first step: record the production order, re-lay the buckets after it
 
     # -- bucket layout ------------------------------------------------------------------------------------------------
-    def _build(self, device: torch.device) -> None:
-        known = {id(p) for p in self._order}
-        order = self._order + [p for p in self.params if id(p) not in known]      # never-produced parameters go last
+    def _build(self, device: torch.device, order_hint: Optional[List[torch.nn.Parameter]] = None) -> None:
+        base = self._order if order_hint is None else order_hint
+        known = {id(p) for p in base}
+        order = list(base) + [p for p in self.params if id(p) not in known]       # never-produced parameters go last
         self._slots, sizes = {}, []
         cur, used = 0, 0
         for p in order:
@@ -135,21 +136,24 @@ class GradientReducer:
     # -- per step -----------------------------------------------------------------------------------------------------
     def start(self) -> None:
         self._works = []
-        self._first = {}
-        if self._slots is not None:
-            self._remaining = list(self._members)
-            for b in self._buckets:
-                b.zero_()
+        if self._slots is None:
+            # first step: the production order is not known yet -- lay the buckets out in REVERSE registration order (the guess
+            # torch's DDP makes too: the backward visits the modules roughly back to front), so step 1 already overlaps; the
+            # observed order replaces it after the step
+            self._build(self.params[0].device, order_hint=list(reversed(self.params)))
+        self._remaining = list(self._members)
+        for b in self._buckets:
+            b.zero_()
 
     def push(self, grads: Dict[torch.nn.Parameter, torch.Tensor]) -> None:
+        """Scale the gradients into their bucket slots ON THE CALLER'S CURRENT STREAM (the weight-gradient side stream during the
+        backward) and start the all-reduce of every bucket that became complete; the collective is ordered after that stream."""
         scale = 1.0 / self.world
         for p, g in grads.items():
             if g is None or not p.requires_grad:
                 continue
-            if self._slots is None:                       # first step: record the order, reduce everything in finish()
+            if self._observing:
                 self._order.append(p)
-                self._first[id(p)] = g
-                continue
             b, off, n = self._slots[id(p)]
             self._buckets[b][off:off + n].copy_(g.reshape(-1)).mul_(scale)
             self._remaining[b] -= 1
@@ -157,23 +161,11 @@ class GradientReducer:
                 self._works.append(dist.all_reduce(self._buckets[b], group=self.group, async_op=True))
 
     def finish(self) -> Dict[torch.nn.Parameter, torch.Tensor]:
-        if self._slots is None:                           # first step: lay the buckets out, then one synchronous pass
-            dev = next(iter(self._first.values())).device if self._first else self.params[0].device
-            self._build(dev)
-            first = self._first
-            self.start()
-            scale = 1.0 / self.world
-            for p in self.params:
-                g = first.get(id(p))
-                if g is not None:
-                    b, off, n = self._slots[id(p)]
-                    self._buckets[b][off:off + n].copy_(g.reshape(-1)).mul_(scale)
-            if self.world > 1:
-                self._works = [dist.all_reduce(bk, group=self.group, async_op=True) for bk in self._buckets]
-        elif self.world > 1:
+        if self.world > 1:
             for b, left in enumerate(self._remaining):    # buckets holding parameters nobody produced this step
                 if left > 0:
                     self._works.append(dist.all_reduce(self._buckets[b], group=self.group, async_op=True))
+                    self._remaining[b] = 0
         for w in self._works:
             w.wait()
         self._works = []
@@ -184,6 +176,9 @@ class GradientReducer:
         for p in self.params:
             b, off, n = self._slots[id(p)]
             out[p] = self._buckets[b][off:off + n].clone().view_as(p)
+        if self._observing:                               # from step 2 on: buckets in the order the backward really produced them
+            self._observing = False
+            self._build(self._buckets[0].device)
         return out
 
 

@@ -113,11 +113,13 @@ def _side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
 def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1, in_slope: Optional[float] = None,
                 cvalid: Optional[int] = None, reducer=None) -> None:
     """dW, db of one conv from its forward input and output gradient (NHWC); handed to the gradient reducer at once (DDP runs)."""
-    side = _side_stream(dy.device) if reducer is None else None
+    side = _side_stream(dy.device)
     if side is None:
         new = {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
         if conv.bias is not None:
             new[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+        if reducer is not None:
+            reducer.push(new)
     else:
         main = torch.cuda.current_stream(dy.device)
         side.wait_stream(main)                              # dy (and x_in) are complete on the main stream up to here
@@ -125,13 +127,13 @@ def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1,
             new = {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
             if conv.bias is not None:
                 new[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+            if reducer is not None:
+                reducer.push(new)                           # bucket copies + all-reduce start behind the wgrad kernels, on THEIR stream
         for t in (x_in, dy):
             t.record_stream(side)                           # the caching allocator must not recycle them under the side stream
         for g in new.values():
             g.record_stream(main)                           # allocated on the side stream, consumed (after the join) on the main one
     grads.update(new)
-    if reducer is not None:
-        reducer.push(new)
 
 
 def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[Tensor], reducer=None) -> Dict:
@@ -160,10 +162,20 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
             elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
                 dbridge[aux] = dx
                 s2d = ops.space_to_depth2(dx)
-                new = {mod.weight: ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True), mod.bias: ops.colsum(dx)}
+                side = _side_stream(dx.device)
+                main = torch.cuda.current_stream(dx.device)
+                if side is not None:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):        # same stream as every other push (bucket order)
+                    new = {mod.weight: ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True), mod.bias: ops.colsum(dx)}
+                    if reducer is not None:
+                        reducer.push(new)
+                if side is not None:
+                    for t in (x_in, s2d, dx):
+                        t.record_stream(side)
+                    for g in new.values():
+                        g.record_stream(main)
                 grads.update(new)
-                if reducer is not None:
-                    reducer.push(new)
                 dx, _ = ops.conv_mfma(s2d, mod.packed_dgrad(), want_raw=True)
             else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
                 _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer)
