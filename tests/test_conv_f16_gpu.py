@@ -120,7 +120,8 @@ def test_f16x3_abi_rejects_bad_descriptors():
         return nat.ConvDesc(**d)
     lib = nat.load()
     assert lib.virnet_conv_f16(C.byref(desc()), nat.stream_handle()) == 0
-    for bad in (dict(stride=2), dict(ks=1), dict(cout=48, n_pad=48), dict(epi=nat.EPI_NCHW), dict(y_raw=0), dict(cin_pad=24), dict(in_mul=nat.ptr(x))):
+    for bad in (dict(stride=3), dict(stride=2, res=nat.ptr(y)), dict(stride=2, h=3), dict(ks=1), dict(cout=48, n_pad=48), dict(epi=nat.EPI_NCHW),
+                dict(y_raw=0), dict(cin_pad=24), dict(in_mul=nat.ptr(x))):
         assert lib.virnet_conv_f16(C.byref(desc(**bad)), nat.stream_handle()) != 0, bad
         assert lib.virnet_last_error()
     torch.cuda.synchronize()
@@ -203,3 +204,37 @@ def test_f16x3_entry_conv_single_chunk(cin, cout, h, w, n):
     raw, _ = ops.conv_mfma(xr, pw, want_raw=True)
     _, act = ops.conv_mfma(xr, pw, want_raw=False, want_act=True, slope=0.25)
     assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(96, 192, 16, 64, 2), (192, 288, 10, 14, 1), (96, 160, 8, 70, 2), (160, 224, 6, 6, 1), (64, 96, 34, 66, 1),
+                                             (32, 32, 2, 2, 1), (48, 64, 12, 36, 3), (96, 192, 64, 128, 4)])
+def test_f16x3_stride2_down_conv(monkeypatch, cin, cout, h, w, n):
+    """DownBlock.downsampler (AttResUNet.py:67,74) on the split-fp16 stride-2 kernel: 8-wave (6 slabs) and 4-wave (3 / 2 / 1 slabs)
+    workgroup forms, partial tiles, odd chunk counts, raw and activated single stores -- against the oracle and the fp32 direct kernel."""
+    cp = make_conv(cin, cout, stride=2, seed=60)
+    x = rnd(n, cin, h, w, seed=61)
+    raw_ref, act_ref = cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach(), stride=2, slope=0.2)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.f16 is not None
+    with ops_timer() as t:
+        raw, _ = ops.conv_mfma(nhwc(x), pw, stride=2, want_raw=True)
+    assert [k[0] for k in t.summary()] == ["f16x3_s2"]
+    _, act = ops.conv_mfma(nhwc(x), pw, stride=2, want_raw=False, want_act=True, slope=0.2)
+    assert tuple(raw.shape) == (n, h // 2, w // 2, cout)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+    monkeypatch.setenv("VIRNET_CONV_FORM", "direct")
+    raw_d, _ = ops.conv_mfma(nhwc(x), cp.packed(), stride=2, want_raw=True)
+    assert maxerr(raw.cpu(), raw_d.cpu()) <= TOL
+
+
+class ops_timer:
+    """Context manager: route the launches through ops.LaunchTimer to see which kernel form ran."""
+    def __enter__(self):
+        self.t = ops.LaunchTimer()
+        ops.set_launch_timer(self.t)
+        return self.t
+
+    def __exit__(self, *exc):
+        ops.set_launch_timer(None)
+        return False

@@ -26,64 +26,12 @@
 // One barrier per tap group (54 MFMAs per wave at 2x3 blocks); two workgroups per CU cover each other's barriers and epilogues.
 // Epilogue: inverse scale, bias, mask, residual, activation as conv_mfma.hip, after a per-wave LDS turn-around of each 32-channel slab
 // that makes every residual load and store a run of whole 128-B lines.
-#include "common.h"
-#include "../../include/virnet_hip.h"
+#include "conv_f16_common.h"
 #include <cstdlib>
 #include <type_traits>
 
 namespace {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-#define SB() __builtin_amdgcn_sched_barrier(0)
-// -DVIRNET_F16_TIMING: wave 0 of every workgroup logs s_memtime at start / after the prologue / after the K loop / at exit plus
-// its HW_ID and XCC_ID into the buffer given to virnet_debug_timing_buffer (tools/f16_timeline.py reads it).
-#ifdef VIRNET_F16_TIMING
-#define TSTAMP(i) do { if (a.tlog && tid == 0) a.tlog[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define TSTAMP(i) do { } while (0)
-#endif
-
-struct FArgs {
-  const float* x;
-  const char* wimg;        // [slab][chunk][tap'][hi|lo][lane][16 B]
-  const float* inv_scale;  // [NP]
-  const float* bias;
-  const float* res;
-  const float* mul;
-  const float* add;
-  const float* in_mul;
-  const float* in_add;
-  const float* mask;
-  float* y_raw;
-  float* y_act;
-  int N, H, W, Cin;
-  int NP, cout;            // NP: GEMM rows (output channels) covered by THIS launch, starting at slab `slab_base`
-  int slab_base;
-  int ntx, nty, ntiles, tiles_per_xcd;
-  int in_act;
-  int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
-  float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
-  long long* tlog;
-};
-
-__device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
-  const f32x4 t = u * s;
-  return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
-}
-
-// v = hi + lo in fp16 (round to nearest even both times)
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h8& lo) {
-  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    hi[e] = (_Float16)v[e];
-    lo[e] = (_Float16)(v[e] - (float)hi[e]);
-  }
-}
+using namespace virnet;
 
 // EPI specialises the epilogue so its loads are straight-line code the compiler can count (a runtime `if (ptr) load` merges into a
 // vmcnt(0) before every store, which serialises the stores on their acknowledgements -- measured: 7 k cycles per slab):
@@ -583,8 +531,8 @@ extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int c
 extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
-  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW),
-                 "virnet_conv_f16: only the stride-1 3x3 conv with NHWC or planar store (ks=%d stride=%d epi=%d)", d->ks, d->stride, d->epi);
+  VIRNET_REQUIRE(d->ks == 3 && ((d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW)) || (d->stride == 2 && d->epi == VIRNET_EPI_NHWC)),
+                 "virnet_conv_f16: 3x3 conv, stride 1 (NHWC or planar store) or stride 2 (NHWC) (ks=%d stride=%d epi=%d)", d->ks, d->stride, d->epi);
   VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_f16: empty input n=%d h=%d w=%d", d->n, d->h, d->w);
   VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_f16: cin_pad=%d is not a multiple of 16", d->cin_pad);
   if (d->epi == VIRNET_EPI_NCHW) {
@@ -615,6 +563,14 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   k.tlog = g_tlog;
 #endif
   hipStream_t st = static_cast<hipStream_t>(stream);
+  k.OH = d->h; k.OW = d->w;
+  if (d->stride == 2) {                                         // DownBlock.downsampler (AttResUNet.py:67): conv_f16_s2.hip
+    VIRNET_REQUIRE(d->h % 2 == 0 && d->w % 2 == 0, "virnet_conv_f16: stride-2 input %dx%d must be even", d->h, d->w);
+    VIRNET_REQUIRE(!d->res && !d->mask && !d->mul && !d->in_mul && !(d->y_raw && d->y_act),
+                   "virnet_conv_f16: the stride-2 form has the bias / single-store epilogue only");
+    k.OH = d->h / 2; k.OW = d->w / 2;
+    return virnet::launch_f16_s2(k, d->n_pad / 32, st);
+  }
   const int nb = d->n_pad / 32;
   const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
   const char* const env_m = getenv("VIRNET_F16_MREP");      // tuning / tests (read per call)

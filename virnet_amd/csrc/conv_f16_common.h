@@ -1,0 +1,66 @@
+// conv_f16_common.h -- argument block and small device helpers shared by the split-fp16 convolution kernels
+// (conv_f16.hip: stride 1; conv_f16_s2.hip: stride 2).  See conv_f16.hip for the arithmetic.
+#pragma once
+#include "common.h"
+#include "../../include/virnet_hip.h"
+
+namespace virnet {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+// -DVIRNET_F16_TIMING: wave 0 of every workgroup logs s_memtime at start / after the prologue / after the K loop / at exit plus
+// its HW_ID and XCC_ID into the buffer given to virnet_debug_timing_buffer (tools/f16_timeline.py reads it).
+#ifdef VIRNET_F16_TIMING
+#define TSTAMP(i) do { if (a.tlog && tid == 0) a.tlog[(size_t)blockIdx.x * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
+struct FArgs {
+  const float* x;
+  const char* wimg;        // [slab][chunk][tap'][hi|lo][lane][16 B]
+  const float* inv_scale;  // [NP]
+  const float* bias;
+  const float* res;
+  const float* mul;
+  const float* add;
+  const float* in_mul;
+  const float* in_add;
+  const float* mask;
+  float* y_raw;
+  float* y_act;
+  int N, H, W, Cin;
+  int OH, OW;              // output size (stride-2 form; the stride-1 kernel uses H, W)
+  int NP, cout;            // NP: GEMM rows (output channels) covered by THIS launch, starting at slab `slab_base`
+  int slab_base;
+  int ntx, nty, ntiles, tiles_per_xcd;
+  int in_act;
+  int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
+  float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
+  long long* tlog;
+};
+
+__device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
+  const f32x4 t = u * s;
+  return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
+}
+
+// v = hi + lo in fp16 (round to nearest even both times)
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hi[e] = (_Float16)v[e];
+    lo[e] = (_Float16)(v[e] - (float)hi[e]);
+  }
+}
+
+
+// stride-2 form (conv_f16_s2.hip): `k` filled as for the stride-1 launch, H/W = INPUT size, OH/OW = output size; nb = 32-channel slabs
+int launch_f16_s2(FArgs k, int nb, hipStream_t st);
+
+}  // namespace virnet
