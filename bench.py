@@ -218,8 +218,8 @@ def main():
                 return "conv3x3_thin<cout=%d>" % k[3]
             if k[0] == "wgrad":
                 return "conv_wgrad<ks=%d,s=%d,t=%d>" % k[1:]
-            if k[0] in ("wino", "f16x3", "f16x3_s2"):
-                return "conv_%s<cout=%d>" % ({"f16x3": "f16", "f16x3_s2": "f16_s2", "wino": "wino"}[k[0]], k[1])
+            if k[0] in ("wino", "f16x3", "f16x3_s2", "f16x3_t"):
+                return "conv_%s<cout=%d>" % ({"f16x3": "f16", "f16x3_s2": "f16_s2", "f16x3_t": "f16_pw(convT)", "wino": "wino"}[k[0]], k[1])
             return "conv_mfma<%d,%d,%d,%d>" % k
         # dominant kernel = the launch group of the stride-1 3x3 res-block convs with the most time
         cands = ([k for k in summ if k[0] in ("wino", "f16x3")] or [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3]

@@ -136,6 +136,14 @@ int virnet_conv_wino(const virnet_conv_desc* d, void* stream);
 size_t virnet_f16_weight_floats(int cin_pad, int n_pad);
 int virnet_pack_f16_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
 int virnet_conv_f16(const virnet_conv_desc* d, void* stream);
+/* The other two dense layers of the U-Net on the same pipe, through virnet_conv_f16:
+ *   - ks = 3, stride = 2, epi = VIRNET_EPI_NHWC (DownBlock.downsampler, AttResUNet.py:67,74): `wpack` from virnet_pack_f16_weight,
+ *     bias / single-store epilogue only (csrc/conv_f16_s2.hip);
+ *   - ks = 1, epi = VIRNET_EPI_CONVT (UpBlock.upsampler + bridge add, AttResUNet.py:80,84-87): `wpack` from
+ *     virnet_pack_f16_convt_weight (the IOHW [cin][cout][2][2] tensor as the pointwise GEMM to rows (a*2+b)*cout + co, contraction
+ *     zero-padded to a multiple of 48), n_pad = 4*cout, bias + `res` (bridge) / single-store epilogue (csrc/conv_f16_pw.hip). */
+size_t virnet_f16_convt_weight_floats(int cin, int cout);
+int virnet_pack_f16_convt_weight(const float* w_iohw, int cout, int cin, float* packed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):

@@ -238,3 +238,27 @@ class ops_timer:
     def __exit__(self, *exc):
         ops.set_launch_timer(None)
         return False
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(288, 192, 8, 16, 2), (192, 96, 7, 9, 1), (224, 160, 5, 5, 2), (160, 96, 6, 33, 1), (64, 32, 3, 3, 1),
+                                             (96, 64, 16, 16, 3), (288, 192, 32, 32, 4)])
+def test_f16x3_transposed_conv(monkeypatch, cin, cout, h, w, n):
+    """UpBlock.upsampler + bridge (AttResUNet.py:80,84-87) on the split-fp16 pointwise kernel: contraction lengths that are and are not
+    multiples of 48 (zero-padded stages), 8-wave / 4-wave forms, partial pixel tiles, with and without the bridge, activated store."""
+    cp = make_conv(cin, cout, ks=2, stride=2, transposed=True, seed=63)
+    x, bridge = rnd(n, cin, h, w, seed=64), rnd(n, cout, 2 * h, 2 * w, seed=65)
+    raw_ref, act_ref = cpu_ref.conv_transpose_fused(x, cp.weight.detach(), cp.bias.detach(), bridge, slope=0.2)
+    plain_ref = F.conv_transpose2d(x, cp.weight.detach(), cp.bias.detach(), stride=2)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.f16 is not None
+    with ops_timer() as t:
+        raw, _ = ops.conv_mfma(nhwc(x), pw, res=nhwc(bridge), want_raw=True)
+    assert [k[0] for k in t.summary()] == ["f16x3_t"]
+    _, act = ops.conv_mfma(nhwc(x), pw, res=nhwc(bridge), want_raw=False, want_act=True, slope=0.2)
+    plain, _ = ops.conv_mfma(nhwc(x), pw, want_raw=True)
+    assert tuple(raw.shape) == (n, 2 * h, 2 * w, cout)
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL and maxerr(nchw(plain), plain_ref) <= TOL
+    monkeypatch.setenv("VIRNET_CONV_FORM", "direct")
+    raw_d, _ = ops.conv_mfma(nhwc(x), cp.packed(), res=nhwc(bridge), want_raw=True)
+    assert maxerr(raw.cpu(), raw_d.cpu()) <= TOL

@@ -531,6 +531,18 @@ extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int c
 extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
+  if (d->ks == 1 && d->epi == VIRNET_EPI_CONVT) {                // UpBlock.upsampler + bridge (AttResUNet.py:80,84-87): conv_f16_pw.hip
+    VIRNET_REQUIRE(d->stride == 1 && d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_f16: bad transposed-conv shape");
+    VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == 4 * d->cout, "virnet_conv_f16: transposed conv needs cout %% 32 == 0 and n_pad = 4*cout (cout=%d n_pad=%d)", d->cout, d->n_pad);
+    VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_f16: cin_pad=%d is not a multiple of 16", d->cin_pad);
+    VIRNET_REQUIRE((d->y_raw != nullptr) != (d->y_act != nullptr) && !d->mask && !d->mul && !d->in_mul, "virnet_conv_f16: the transposed form has the bias + bridge / single-store epilogue only");
+    VIRNET_REQUIRE((long)d->h * d->w * d->cout * 16 * d->n < (1L << 40), "virnet_conv_f16: output too large");
+    FArgs t{};
+    t.x = d->x; t.inv_scale = d->wpack; t.wimg = reinterpret_cast<const char*>(d->wpack + d->n_pad);
+    t.bias = d->bias; t.res = d->res; t.y_raw = d->y_raw; t.y_act = d->y_act;
+    t.N = d->n; t.H = d->h; t.W = d->w; t.cout = d->cout; t.in_act = d->in_act; t.in_slope = d->in_slope; t.slope = d->slope;
+    return virnet::launch_f16_convt(t, d->cin_pad, static_cast<hipStream_t>(stream));
+  }
   VIRNET_REQUIRE(d->ks == 3 && ((d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW)) || (d->stride == 2 && d->epi == VIRNET_EPI_NHWC)),
                  "virnet_conv_f16: 3x3 conv, stride 1 (NHWC or planar store) or stride 2 (NHWC) (ks=%d stride=%d epi=%d)", d->ks, d->stride, d->epi);
   VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_f16: empty input n=%d h=%d w=%d", d->n, d->h, d->w);

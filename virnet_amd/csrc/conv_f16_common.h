@@ -62,5 +62,7 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h
 
 // stride-2 form (conv_f16_s2.hip): `k` filled as for the stride-1 launch, H/W = INPUT size, OH/OW = output size; nb = 32-channel slabs
 int launch_f16_s2(FArgs k, int nb, hipStream_t st);
+// transposed 2x2/s2 conv as a pointwise GEMM + depth-to-space store (conv_f16_pw.hip)
+int launch_f16_convt(FArgs k, int cin_real, hipStream_t st);
 
 }  // namespace virnet

@@ -66,7 +66,7 @@ def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct
         nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
     if form != "direct":
-        key = (form + ("_s2" if d.stride == 2 else ""), d.cout)
+        key = (form + ("_s2" if d.stride == 2 else "_t" if d.epi == nat.EPI_CONVT else ""), d.cout)
     else:
         var = (C.c_int * 4)()
         nat.check(lib.virnet_conv_mfma_variant(C.byref(d), C.byref(var)), what)
@@ -205,6 +205,9 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         b = bias.detach()
         _dev_check(b, "bias")
     pw = PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
+    if transposed and conv_form() == "f16x3" and cout % 32 == 0 and cin % 16 == 0:
+        pw.f16 = torch.empty(lib.virnet_f16_convt_weight_floats(cin, cout), dtype=torch.float32, device=weight.device)
+        nat.check(lib.virnet_pack_f16_convt_weight(nat.ptr(weight), cout, cin, nat.ptr(pw.f16), nat.stream_handle()), "pack_f16_convt_weight")
     if kind == 0 and ks == 3 and stride == 2 and conv_form() == "f16x3" and cout % 32 == 0 and cin % 16 == 0:
         pw.f16 = pack_f16_weight(weight)                     # DownBlock.downsampler: csrc/conv_f16_s2.hip (same image)
     if kind == 0 and ks == 3 and stride == 1:
@@ -249,7 +252,10 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
     if res is not None and tuple(res.shape) != (n, oh, ow, cstore):
         raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, cstore)}")
     form = "direct"
-    if (stride == 2 and epi == nat.EPI_NHWC and cstore == pw.cout and pw.f16 is not None and conv_form() == "f16x3" and res is None
+    if (pw.transposed and pw.f16 is not None and conv_form() == "f16x3" and mask is None and mul is None and in_mul is None
+            and want_raw != want_act):
+        form = "f16x3"
+    elif (stride == 2 and epi == nat.EPI_NHWC and cstore == pw.cout and pw.f16 is not None and conv_form() == "f16x3" and res is None
             and mask is None and mul is None and in_mul is None and not (want_raw and want_act)):
         form = "f16x3"
     elif stride == 1 and epi == nat.EPI_NHWC and cstore == pw.cout:
