@@ -52,6 +52,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md:
 F16_MFMA_PEAK_TFLOPS = 2500.0          # same guide: BF16/F16 MFMA ~2.5 PFLOP/s dense (16x the fp32 matrix rate)
 # matrix-pipe FLOPs executed per algorithmic FLOP (2*MAC of the direct 3x3 convolution), and the pipe they run on
 FORMS = {"f16x3": (3.0, F16_MFMA_PEAK_TFLOPS, "split-fp16 operands: 3 products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation"),
+         "bf16": (1.0, F16_MFMA_PEAK_TFLOPS, "bf16-rounded operands: 1 product per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulation (C->C 3x3 convs "
+                                            "forward + input gradients; weight gradients fp32 MFMA, other layers split-fp16)"),
          "wino": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS, "Winograd F(2x2,3x3), fp32: 16/36 of the algorithmic MACs on v_mfma_f32_32x32x2_f32"),
          "direct": (1.0, FP32_MFMA_PEAK_TFLOPS, "direct implicit GEMM, fp32 on v_mfma_f32_32x32x2_f32")}
 KFLOP_PER_PIXEL = 4988.736             # conv FLOPs (2*MAC) of the denoise-syn forward per padded pixel
@@ -121,11 +123,18 @@ def main():
                     help="sisr = BASELINE configs[3]: VIRAttResUNetSR x4 on LR 64x64 (-> 256x256), 16 images per GPU; "
                          "train = configs[4]: denoise-syn forward + ELBO + backward (+Adam with --optimizer) on 128x128, 32 per GPU, fp32")
     ap.add_argument("--optimizer", action="store_true", help="train task: include grad clipping + Adam step in the timed step")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="train task: bf16 = BASELINE configs[4]'s variant -- the C->C 3x3 convs of forward and backward (input gradients) run "
+                         "with bf16-rounded operands, one product per MAC, fp32 accumulation; weight gradients and all other layers stay fp32-class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     sisr = args.task == "sisr"
     training = args.task == "train"
+    if args.dtype == "bf16":
+        if not training:
+            raise SystemExit("--dtype bf16 is the training variant (inference must be fp32-class: BASELINE.md, 7.5e-3 error at bf16)")
+        os.environ["VIRNET_CONV_FORM"] = "bf16"
     if sisr and args.size == 256:
         args.size = 64                      # LR size; the output is 4x
     if training and args.size == 256:
@@ -218,11 +227,11 @@ def main():
                 return "conv3x3_thin<cout=%d>" % k[3]
             if k[0] == "wgrad":
                 return "conv_wgrad<ks=%d,s=%d,t=%d>" % k[1:]
-            if k[0] in ("wino", "f16x3", "f16x3_s2", "f16x3_t"):
-                return "conv_%s<cout=%d>" % ({"f16x3": "f16", "f16x3_s2": "f16_s2", "f16x3_t": "f16_pw(convT)", "wino": "wino"}[k[0]], k[1])
+            if k[0] in ("wino", "f16x3", "f16x3_s2", "f16x3_t", "bf16"):
+                return "conv_%s<cout=%d>" % ({"f16x3": "f16", "f16x3_s2": "f16_s2", "f16x3_t": "f16_pw(convT)", "wino": "wino", "bf16": "bf16"}[k[0]], k[1])
             return "conv_mfma<%d,%d,%d,%d>" % k
         # dominant kernel = the launch group of the stride-1 3x3 res-block convs with the most time
-        cands = ([k for k in summ if k[0] in ("wino", "f16x3")] or [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3]
+        cands = ([k for k in summ if k[0] in ("wino", "f16x3", "bf16")] or [k for k in summ if k[0] == 3 and k[1] == 1 and k[3] == 3]
                  or [k for k in summ if k[0] == 3 and k[1] == 1])
         dom = max(cands, key=lambda k: summ[k]["ms"]) if cands else None
         d = summ.get(dom)
@@ -233,7 +242,8 @@ def main():
             algorithmic = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             total_ms = sum(v["ms"] for v in summ.values())
             pmc = load_pmc_traffic() if (not sisr and not training and args.size == 256 and batch == 32) else None   # measured on this workload only
-            kern = {"f16x3": "conv_f16_kernel<MREP,NREP> (3x3 stride-1, %d channels)" % dom[1],
+            kern = {"f16x3": "conv_f16_kernel<MREP,NREP,EPI> (3x3 stride-1, %d channels)" % dom[1],
+                    "bf16": "conv_f16_kernel<MREP,NREP,EPI,BF=1> (3x3 stride-1, %d channels, bf16 operands)" % dom[1],
                     "wino": "conv_wino_row_kernel<G,false,WPU> (3x3 stride-1, %d channels)" % dom[1]}.get(form) or "conv_mfma_kernel<%d,%d,%d,%d>" % dom
             roof = {"bound": "mfma", "achieved": round(algorithmic * factor, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(algorithmic * factor / peak, 4),
@@ -263,7 +273,7 @@ def main():
                        "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"VIRAttResUNetSR x4 forward (n_feat 96/160/224, 2 res-blocks, dep_S 5, dep_K 8, extra_mode Both), LR {args.size}x{args.size}x3 "
                                     if sisr else f"VIRAttResUNet denoise-syn forward (n_feat 96/192/288, 3 res-blocks, dep_S 5), {args.size}x{args.size}x3 ")
                                    + f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",

@@ -249,3 +249,40 @@ def test_optimizer_step_and_repack():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+def test_training_step_bf16_operand_variant(monkeypatch):
+    """BASELINE configs[4] as written (bf16): forward + ELBO + backward with VIRNET_CONV_FORM=bf16 -- the C->C 3x3 convs of the forward and
+    of the input-gradient chain take bf16-rounded operands (one product per MAC, fp32 accumulation, fp32 master weights); weight
+    gradients, entries / exits, strided and transposed convs stay fp32-class.  Tolerance: bf16 rounds each operand to 2^-9 relative; through
+    ~40 layers of this network on the synthetic weights that is ~1e-2 on mu (BASELINE.md measured 7.5e-3 for an all-bf16 forward), so
+    loss and gradients are held to 5 % of their scale against the fp32 oracle -- and the step must still descend."""
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    monkeypatch.setenv("VIRNET_CONV_FORM", "bf16")
+    cfg = dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input")
+    net = VIRAttResUNet(**cfg)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    n, c, h, w = 2, 3, 32, 32
+    gt = synth_images(n, c, h, w, seed=1)
+    sig_gt = (rnd(n, 1, h, w, seed=2, lo=0.02, hi=0.3) ** 2).contiguous()
+    noisy = gt + rnd(n, c, h, w, seed=3, lo=-0.3, hi=0.3)
+    mu, sigma = net(noisy.cuda())
+    loss = _elbo(mu, sigma, noisy.cuda(), gt.cuda(), sig_gt.cuda(), eps2=1e-2)
+    loss.backward()
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}
+    mu_r, sigma_r = cpu_ref.virnet_denoise(ref, noisy, **kw)
+    loss_r = _elbo(mu_r, sigma_r, noisy, gt, sig_gt, eps2=1e-2)
+    loss_r.backward()
+    assert 1e-5 < float((mu.detach().cpu() - mu_r.detach()).abs().max()) < 0.1            # really reduced precision, and bounded
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 5e-2 * abs(float(loss_r.detach()))
+    worst = 0.0
+    for name, p in net.named_parameters():
+        g, gr = p.grad.cpu(), ref[name].grad
+        scale = max(float(gr.abs().max()), 1e-12)
+        worst = max(worst, float((g - gr).abs().median()) / scale)
+        assert float((g - gr).abs().median()) / scale <= 5e-2, name
+    assert worst > 1e-5

@@ -262,3 +262,34 @@ def test_f16x3_transposed_conv(monkeypatch, cin, cout, h, w, n):
     monkeypatch.setenv("VIRNET_CONV_FORM", "direct")
     raw_d, _ = ops.conv_mfma(nhwc(x), cp.packed(), res=nhwc(bridge), want_raw=True)
     assert maxerr(raw.cpu(), raw_d.cpu()) <= TOL
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("c,h,w,n", [(96, 17, 70, 1), (64, 9, 33, 2), (192, 12, 31, 2), (160, 5, 7, 1)])
+def test_bf16_operand_variant_is_exactly_bf16_rounded_operands(monkeypatch, c, h, w, n):
+    """VIRNET_CONV_FORM=bf16 (BASELINE configs[4]'s training precision): the kernel must equal an fp32 convolution of the bf16-ROUNDED
+    pre-activated input and bf16-rounded weights (products of bf16 pairs are exact in fp32, so only the summation order differs) --
+    tolerance 2e-5 as for the fp32 forms; against the unrounded fp32 oracle it is off by the stated bf16 operand error (~1e-2)."""
+    monkeypatch.setenv("VIRNET_CONV_FORM", "bf16")
+    cp = make_conv(c, c, seed=80)
+    x, res = rnd(n, c, h, w, seed=81), rnd(n, c, h, w, seed=82)
+    a = _bf16_round(F.leaky_relu(x, 0.2))
+    raw_ref, act_ref = cpu_ref.conv_fused(a, _bf16_round(cp.weight.detach()), cp.bias.detach(), residual=res, slope=0.25)
+    raw_f32, _ = cpu_ref.conv_fused(F.leaky_relu(x, 0.2), cp.weight.detach(), cp.bias.detach(), residual=res, slope=0.25)
+    cp.cuda()
+    pw = cp.packed()
+    assert pw.bf16 is not None and pw.f16 is not None
+    with ops_timer() as t:
+        raw, act = ops.conv_mfma(nhwc(x), pw, in_slope=0.2, res=nhwc(res), want_raw=True, want_act=True, slope=0.25)
+    assert [k[0] for k in t.summary()] == ["bf16"]
+    assert maxerr(nchw(raw), raw_ref) <= TOL and maxerr(nchw(act), act_ref) <= TOL
+    e32 = maxerr(nchw(raw), raw_f32)
+    assert 1e-4 < e32 < 5e-2, e32
+    # input-gradient GEMM through the same variant
+    dy, saved = rnd(n, c, h, w, seed=91), rnd(n, c, h, w, seed=92)
+    ref = F.conv_transpose2d(_bf16_round(dy), _bf16_round(cp.weight.detach().cpu()), padding=1) * torch.where(saved > 0, 1.0, 0.2)
+    dx, _ = ops.conv_mfma(nhwc(dy), cp.packed_dgrad(), mask=nhwc(saved), mask_slope=0.2, want_raw=True)
+    assert maxerr(nchw(dx), ref) <= TOL

@@ -38,7 +38,9 @@ using namespace virnet;
 //   bit 0 = residual, bit 1 = LeakyReLU-derivative mask (backward), one stored tensor; 4 = everything by runtime pointer (two
 //   stored tensors, SFT on the output); 5 = planar NCHW store of <= 32 channels with crop and `+ x_in` / exp(clamp) (NREP = 1:
 //   AttResUNet.tail, AttResUNet.py:139,173; DnCNN.conv_last, DnCNN.py:29 + VIRNet.py:43; KernelNet.tail, KNet.py:49).
-template <int MREP, int NREP, int EPI>
+// BF = 1: the bf16-operand variant (BASELINE configs[4]'s training precision): ONE product per MAC on v_mfma_f32_32x32x16_bf16, operands
+// rounded to bf16 while they are staged (weights when they are packed), no low halves anywhere; everything else is the same kernel.
+template <int MREP, int NREP, int EPI, int BF = 0>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
   constexpr int NPIECE = NPIX * 2;                 // (pixel, 8-channel half) staging pieces of one chunk
@@ -108,10 +110,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
     r0 = sinb[k] ? r0 : z;
     r1 = sinb[k] ? r1 : z;
-    h8 hi, lo;
-    split8(r0, r1, hi, lo);
-    *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
-    *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
+    if constexpr (BF) {
+      *reinterpret_cast<b8*>(xb + sdst[k]) = to_bf16x8(r0, r1);
+    } else {
+      h8 hi, lo;
+      split8(r0, r1, hi, lo);
+      *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
+      *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
+    }
   };
 
   // ---- weight DMA: piece q = (tap-in-group, slab, hi|lo), 1 KB = the fragment of one MFMA operand; wave w moves pieces w, w+4, ...
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   auto dma_group = [&](int stage, char* wb) {
 #pragma unroll
     for (int i = 0; i < (NDMA + 3) / 4; ++i) {
-      const int qd = i * 4 + wave;
+      const int qd = BF ? 2 * (i * 4 + wave) : i * 4 + wave;        // (bf16 variant: the hi pieces only)
       if (qd < NDMA) {
         const int tg = qd / (NREP * 2), rem = qd - tg * (NREP * 2);
         const char* src = wcb + (size_t)(rem >> 1) * slab_bytes + (size_t)((stage * 3 + tg) * 2 + (rem & 1)) * 1024;
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       h[nr] = *reinterpret_cast<const h8*>(wb + ((tg * NREP + nr) * 2 + 0) * 1024 + aoff);
-      l[nr] = *reinterpret_cast<const h8*>(wb + ((tg * NREP + nr) * 2 + 1) * 1024 + aoff);
+      if (!BF) l[nr] = *reinterpret_cast<const h8*>(wb + ((tg * NREP + nr) * 2 + 1) * 1024 + aoff);
     }
   };
   auto read_b = [&](const char* xb, int r, int dx) {
     bh[r] = *reinterpret_cast<const h8*>(xb + boff[r][dx]);
-    bl[r] = *reinterpret_cast<const h8*>(xb + PLANE + boff[r][dx]);
+    if (!BF) bl[r] = *reinterpret_cast<const h8*>(xb + PLANE + boff[r][dx]);
   };
 
   // One tap group = kernel column g of chunk c (P = c&1: pixel buffer; weight buffer (P+g)&1; A register set (P + 3g + dy)&1).
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       SB();
       // requests for the next tap: its weights (same group) and the input row it needs first; at the last tap of a column the
       // first rows of the next column (same chunk) -- those registers were last used by tap dy = 1 -- and this group's staging
-      constexpr int NRD = 2 * NREP + 2;
+      constexpr int NRD = BF ? NREP + 1 : 2 * NREP + 2;
       if (dy < 2) {
         read_a(wb, dy + 1, ah[cur ^ 1], al[cur ^ 1]);
         read_b(xb, MREP + dy, g);
@@ -220,17 +226,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
         if constexpr (g < PPT) stage_store(xn, cn, g, s0, s1);
       }
 #pragma unroll
-      for (int part = 0; part < 3; ++part)
+      for (int part = BF ? 2 : 0; part < 3; ++part)
 #pragma unroll
         for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
           for (int nr = 0; nr < NREP; ++nr) {
             const h8 wa = (part == 0) ? al[cur][nr] : ah[cur][nr];
             const h8 xv = (part == 1) ? bl[mr + dy] : bh[mr + dy];
-            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[mr][nr], 0, 0, 0);
+            if constexpr (BF)
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, wa), __builtin_bit_cast(b8, xv), acc[mr][nr], 0, 0, 0);
+            else
+              acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[mr][nr], 0, 0, 0);
           }
       // interleave: one MFMA, then one LDS read (taps 0, 1) or a handful of staging VALU ops (tap 2)
-      constexpr int NM = 3 * MREP * NREP;
+      constexpr int NM = (BF ? 1 : 3) * MREP * NREP;
       if (dy < 2) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
@@ -241,10 +250,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (g < 2 && i < 2 * MREP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+          if (g < 2 && i < (BF ? 1 : 2) * MREP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x002, BF ? 8 : 5, 0);
         }
-        if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        if (g < PPT) __builtin_amdgcn_sched_group_barrier(0x200, BF ? 1 : 2, 0);
       }
     }
     SB();
@@ -445,14 +454,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #endif
 }
 
-template <int MREP, int NREP, int EPI>
+template <int MREP, int NREP, int EPI, int BF = 0>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);       // K loop: pixel tiles + weight stages
   constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144);                  // epilogue: two turn-around regions per wave
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static unsigned long long attr_done = 0;
-  auto kern = conv_f16_kernel<MREP, NREP, EPI>;
+  auto kern = conv_f16_kernel<MREP, NREP, EPI, BF>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16): %s", hipGetErrorString(e));
@@ -470,8 +479,9 @@ int launch(FArgs k, hipStream_t st) {
 // ---- weight packing -------------------------------------------------------------------------------------------------------
 // One block per GEMM row (output channel): power-of-two scale from the row's largest magnitude, then the split image.
 // kind 0: forward OIHW; kind 2: the layer's input-gradient GEMM (rows = forward cin, contraction = forward cout, flipped taps).
+// bf = 1: the bf16-operand image (one bf16 value in the hi plane, scale 1, lo plane zero).
 __global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout, int cin, int cin_pad, int n_pad,
-                                float* __restrict__ inv_scale, char* __restrict__ img) {
+                                float* __restrict__ inv_scale, char* __restrict__ img, int bf) {
   const int row = blockIdx.x;
   const int rows = kind == 2 ? cin : cout, ks = kind == 2 ? cout : cin;
   const int nch = cin_pad >> 4;
@@ -491,7 +501,7 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout,
   m = red[0];
   // largest scaled magnitude in [8192, 16384): two bits of headroom below fp16's 65504, low halves normal down to 2^-17 of it
   int e = 0;
-  if (m > 0.f) { frexpf(m, &e); e = 14 - e; }
+  if (m > 0.f && !bf) { frexpf(m, &e); e = 14 - e; }
   e = max(-100, min(100, e));
   const float scale = ldexpf(1.f, e);
   if (threadIdx.x == 0) inv_scale[row] = ldexpf(1.f, -e);
@@ -499,12 +509,16 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout,
   for (int i = threadIdx.x; i < cin_pad * 9; i += blockDim.x) {
     const int k = i / 9, t = i % 9, dy = t / 3, dx = t % 3;
     const float v = wval(k, dy, dx) * scale;
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
     const int chunk = k >> 4, kk = k & 15;
     const size_t base = ((((size_t)slab * nch + chunk) * 9 + (dx * 3 + dy)) * 2) * 1024 + (size_t)(col + 32 * (kk >> 3)) * 16 + (kk & 7) * 2;
-    *reinterpret_cast<_Float16*>(img + base) = hi;
-    *reinterpret_cast<_Float16*>(img + base + 1024) = lo;
+    if (bf) {
+      *reinterpret_cast<__bf16*>(img + base) = (__bf16)v;
+      *reinterpret_cast<unsigned short*>(img + base + 1024) = 0;
+    } else {
+      const _Float16 hi = (_Float16)v;
+      *reinterpret_cast<_Float16*>(img + base) = hi;
+      *reinterpret_cast<_Float16*>(img + base + 1024) = (_Float16)(v - (float)hi);
+    }
   }
 }
 
@@ -524,11 +538,34 @@ extern "C" int virnet_pack_f16_weight(const float* w, int dgrad, int cout, int c
   VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= ks, "virnet_pack_f16_weight: cin_pad=%d does not cover %d contraction channels", cin_pad, ks);
   VIRNET_REQUIRE(n_pad % 32 == 0 && n_pad >= rows, "virnet_pack_f16_weight: n_pad=%d does not cover %d output channels", n_pad, rows);
   hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)n_pad), dim3(256), 0, static_cast<hipStream_t>(stream), w, dgrad ? 2 : 0, cout, cin,
-                     cin_pad, n_pad, packed, reinterpret_cast<char*>(packed + n_pad));
+                     cin_pad, n_pad, packed, reinterpret_cast<char*>(packed + n_pad), 0);
   return virnet::check_launch("pack_f16 launch");
 }
 
-extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
+extern "C" int virnet_pack_bf16_weight(const float* w, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream) {
+  VIRNET_REQUIRE(w && packed, "virnet_pack_bf16_weight: NULL pointer");
+  VIRNET_REQUIRE(cout > 0 && cin > 0, "virnet_pack_bf16_weight: bad extents cout=%d cin=%d", cout, cin);
+  const int rows = dgrad ? cin : cout, ks = dgrad ? cout : cin;
+  VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= ks, "virnet_pack_bf16_weight: cin_pad=%d does not cover %d contraction channels", cin_pad, ks);
+  VIRNET_REQUIRE(n_pad % 32 == 0 && n_pad >= rows, "virnet_pack_bf16_weight: n_pad=%d does not cover %d output channels", n_pad, rows);
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)n_pad), dim3(256), 0, static_cast<hipStream_t>(stream), w, dgrad ? 2 : 0, cout, cin,
+                     cin_pad, n_pad, packed, reinterpret_cast<char*>(packed + n_pad), 1);
+  return virnet::check_launch("pack_bf16 launch");
+}
+
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf);
+
+extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) { return conv_f16_impl(d, stream, 0); }
+
+// bf16-operand variant of the stride-1 3x3 NHWC convolution (one product per MAC, fp32 accumulation): wpack from virnet_pack_bf16_weight
+extern "C" int virnet_conv_bf16(const virnet_conv_desc* d, void* stream) {
+  VIRNET_REQUIRE(d != nullptr, "virnet_conv_bf16: desc is NULL");
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_bf16: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
+                 d->ks, d->stride, d->epi);
+  return conv_f16_impl(d, stream, 1);
+}
+
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
   if (d->ks == 1 && d->epi == VIRNET_EPI_CONVT) {                // UpBlock.upsampler + bridge (AttResUNet.py:80,84-87): conv_f16_pw.hip
@@ -605,13 +642,20 @@ extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) {
     kk.NP = groups * nrep * 32;
     int mrep = (tiles8 * groups >= 1024) ? 2 : 1;
     if (forced_m == 1 || forced_m == 2) mrep = forced_m;
-#define VIRNET_F16_CASE(M_, N_)                        \
-    if (mrep == M_ && nrep == N_) {                    \
-      if (epi == 0) return launch<M_, N_, 0>(kk, st);  \
-      if (epi == 1) return launch<M_, N_, 1>(kk, st);  \
-      if (epi == 2) return launch<M_, N_, 2>(kk, st);  \
-      if (epi == 3) return launch<M_, N_, 3>(kk, st);  \
-      return launch<M_, N_, 4>(kk, st);                \
+#define VIRNET_F16_CASE(M_, N_)                                          \
+    if (mrep == M_ && nrep == N_) {                                      \
+      if (bf) {                                                          \
+        if (epi == 0) return launch<M_, N_, 0, 1>(kk, st);               \
+        if (epi == 1) return launch<M_, N_, 1, 1>(kk, st);               \
+        if (epi == 2) return launch<M_, N_, 2, 1>(kk, st);               \
+        if (epi == 3) return launch<M_, N_, 3, 1>(kk, st);               \
+        return launch<M_, N_, 4, 1>(kk, st);                             \
+      }                                                                  \
+      if (epi == 0) return launch<M_, N_, 0>(kk, st);                    \
+      if (epi == 1) return launch<M_, N_, 1>(kk, st);                    \
+      if (epi == 2) return launch<M_, N_, 2>(kk, st);                    \
+      if (epi == 3) return launch<M_, N_, 3>(kk, st);                    \
+      return launch<M_, N_, 4>(kk, st);                                  \
     }
     VIRNET_F16_CASE(2, 3) VIRNET_F16_CASE(2, 2) VIRNET_F16_CASE(2, 1)
     VIRNET_F16_CASE(1, 3) VIRNET_F16_CASE(1, 2) VIRNET_F16_CASE(1, 1)

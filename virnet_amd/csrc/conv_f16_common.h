@@ -7,6 +7,7 @@
 namespace virnet {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -59,6 +60,15 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, h8& hi, h
   }
 }
 
+
+// 8 fp32 -> 8 bf16 (round to nearest even)
+__device__ __forceinline__ b8 to_bf16x8(const f32x4& a, const f32x4& b) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  b8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
+  return r;
+}
 
 // stride-2 form (conv_f16_s2.hip): `k` filled as for the stride-1 launch, H/W = INPUT size, OH/OW = output size; nb = 32-channel slabs
 int launch_f16_s2(FArgs k, int nb, hipStream_t st);

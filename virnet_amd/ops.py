@@ -30,6 +30,7 @@ class PackedWeight:
     transposed: bool
     wino: Optional[Tensor] = None   # Winograd-domain image (virnet_pack_wino_weight) of a stride-1 3x3 layer, when eligible
     f16: Optional[Tensor] = None    # split-fp16 image (virnet_pack_f16_weight) of a stride-1 3x3 layer, when eligible
+    bf16: Optional[Tensor] = None   # bf16-operand image (virnet_pack_bf16_weight) of a C->C stride-1 3x3 layer (form "bf16" only)
 
 
 class LaunchTimer:
@@ -61,7 +62,7 @@ def set_launch_timer(t: Optional[LaunchTimer]) -> None:
 
 def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct") -> None:
     lib = nat.load()
-    fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "direct": lib.virnet_conv_mfma}[form]
+    fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "bf16": lib.virnet_conv_bf16, "direct": lib.virnet_conv_mfma}[form]
     if _TIMER is None:
         nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
@@ -82,6 +83,8 @@ def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct
 #   VIRNET_CONV_FORM=f16x3   split-fp16 operands on the f16 matrix pipe (csrc/conv_f16.hip) -- the default
 #   VIRNET_CONV_FORM=wino    Winograd F(2x2,3x3) on the fp32 matrix pipe (csrc/wino_row.hip)
 #   VIRNET_CONV_FORM=direct  fp32 implicit GEMM (csrc/conv_mfma.hip)
+#   VIRNET_CONV_FORM=bf16    REDUCED precision (BASELINE configs[4]'s training variant): the C->C stride-1 3x3 convs and their input-gradient
+#                            GEMMs with bf16-rounded operands, one product per MAC; every other layer as f16x3
 # (older spelling, honoured when VIRNET_CONV_FORM is unset: VIRNET_WINOGRAD=0 -> direct, VIRNET_WINOGRAD=1 -> wino)
 WINO_MIN_CHANNELS = 32
 DEFAULT_CONV_FORM = "f16x3"
@@ -93,17 +96,22 @@ def conv_form() -> str:
     if form is None:
         legacy = os.environ.get("VIRNET_WINOGRAD")
         form = DEFAULT_CONV_FORM if legacy is None else ("direct" if legacy == "0" else "wino")
-    if form not in ("f16x3", "wino", "direct"):
-        raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected f16x3, wino or direct")
+    if form not in ("f16x3", "wino", "direct", "bf16"):
+        raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected f16x3, wino, direct or bf16")
     return form
+
+
+def _f16_family() -> bool:
+    return conv_form() in ("f16x3", "bf16")
 
 
 def _wino_enabled() -> bool:
     return conv_form() == "wino"
 
 
-def pack_f16_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
-    """Split-fp16 image (+ per-row inverse scales) of an OIHW 3x3 weight for virnet_conv_f16 (``dgrad``: of the input-gradient GEMM)."""
+def pack_f16_weight(weight: Tensor, *, dgrad: bool = False, bf16: bool = False) -> Tensor:
+    """Split-fp16 image (+ per-row inverse scales) of an OIHW 3x3 weight for virnet_conv_f16 (``dgrad``: of the input-gradient GEMM);
+    ``bf16``: the bf16-operand image for virnet_conv_bf16 instead (same size and layout)."""
     lib = nat.load()
     weight = weight.detach()
     _dev_check(weight, "weight")
@@ -114,8 +122,8 @@ def pack_f16_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
     n_pad = (rows + 31) // 32 * 32            # (rows beyond the real ones are zero; the planar store keeps the real channels)
     cin_pad = (ks + 15) // 16 * 16
     out = torch.empty(lib.virnet_f16_weight_floats(cin_pad, n_pad), dtype=torch.float32, device=weight.device)
-    nat.check(lib.virnet_pack_f16_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, n_pad, nat.ptr(out), nat.stream_handle()),
-              "pack_f16_weight")
+    fn = lib.virnet_pack_bf16_weight if bf16 else lib.virnet_pack_f16_weight
+    nat.check(fn(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, n_pad, nat.ptr(out), nat.stream_handle()), "pack_f16_weight")
     return out
 
 
@@ -181,8 +189,10 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         if not transposed and cin % 32 == 0 and cout >= WINO_MIN_CHANNELS:
             if conv_form() == "wino":
                 pw.wino = pack_wino_weight(weight, dgrad=True)
-            elif conv_form() == "f16x3":
+            elif _f16_family():
                 pw.f16 = pack_f16_weight(weight, dgrad=True)
+                if conv_form() == "bf16":
+                    pw.bf16 = pack_f16_weight(weight, dgrad=True, bf16=True)
         return pw
     if transposed:
         cin, cout, kh, kw = weight.shape
@@ -205,18 +215,20 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         b = bias.detach()
         _dev_check(b, "bias")
     pw = PackedWeight(out, b, gemm_ks, cout, cin, plan.cin_pad, plan.n_pad, plan.nrep, transposed)
-    if transposed and conv_form() == "f16x3" and cout % 32 == 0 and cin % 16 == 0:
+    if transposed and _f16_family() and cout % 32 == 0 and cin % 16 == 0:
         pw.f16 = torch.empty(lib.virnet_f16_convt_weight_floats(cin, cout), dtype=torch.float32, device=weight.device)
         nat.check(lib.virnet_pack_f16_convt_weight(nat.ptr(weight), cout, cin, nat.ptr(pw.f16), nat.stream_handle()), "pack_f16_convt_weight")
-    if kind == 0 and ks == 3 and stride == 2 and conv_form() == "f16x3" and cout % 32 == 0 and cin % 16 == 0:
+    if kind == 0 and ks == 3 and stride == 2 and _f16_family() and cout % 32 == 0 and cin % 16 == 0:
         pw.f16 = pack_f16_weight(weight)                     # DownBlock.downsampler: csrc/conv_f16_s2.hip (same image)
     if kind == 0 and ks == 3 and stride == 1:
         if conv_form() == "wino" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
             pw.wino = pack_wino_weight(weight)
-        elif conv_form() == "f16x3" and (cout % 32 == 0 or cout <= 32):
+        elif _f16_family() and (cout % 32 == 0 or cout <= 32):
             # every stride-1 3x3 layer: the C->C convs, the few-input-channel entry convs (HBM-bound: one 16-channel chunk) and, through
             # the planar store, the few-output-channel exits
             pw.f16 = pack_f16_weight(weight)
+            if conv_form() == "bf16" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
+                pw.bf16 = pack_f16_weight(weight, bf16=True)
     return pw
 
 
@@ -252,19 +264,21 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
     if res is not None and tuple(res.shape) != (n, oh, ow, cstore):
         raise ValueError(f"res shape {tuple(res.shape)} != {(n, oh, ow, cstore)}")
     form = "direct"
-    if (pw.transposed and pw.f16 is not None and conv_form() == "f16x3" and mask is None and mul is None and in_mul is None
+    if (pw.transposed and pw.f16 is not None and _f16_family() and mask is None and mul is None and in_mul is None
             and want_raw != want_act):
         form = "f16x3"
-    elif (stride == 2 and epi == nat.EPI_NHWC and cstore == pw.cout and pw.f16 is not None and conv_form() == "f16x3" and res is None
+    elif (stride == 2 and epi == nat.EPI_NHWC and cstore == pw.cout and pw.f16 is not None and _f16_family() and res is None
             and mask is None and mul is None and in_mul is None and not (want_raw and want_act)):
         form = "f16x3"
     elif stride == 1 and epi == nat.EPI_NHWC and cstore == pw.cout:
         want = conv_form()
         if want == "wino" and pw.wino is not None:
             form = "wino"
-        elif want == "f16x3" and pw.f16 is not None and pw.cout % 32 == 0:
+        elif want == "bf16" and pw.bf16 is not None:
+            form = "bf16"
+        elif want in ("f16x3", "bf16") and pw.f16 is not None and pw.cout % 32 == 0:
             form = "f16x3"
-    wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16}[form]
+    wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16, "bf16": pw.bf16}[form]
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
@@ -272,7 +286,7 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
-    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16"}[form], form)
+    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16", "bf16": "conv_bf16"}[form], form)
     return raw, act
 
 
