@@ -212,6 +212,23 @@ typedef struct virnet_wgrad_desc {
   float in_slope;
 } virnet_wgrad_desc;
 int virnet_conv_wgrad(const virnet_wgrad_desc* d, void* stream);
+/* The same gradient for the stride-1 3x3 convs on the f16 matrix pipe (csrc/wgrad_f16.hip; backward of networks/AttResUNet.py:43,46,
+ * DnCNN.py:22-29).  The contraction runs over pixels, so both operands are first re-laid CHANNEL-major as fp16 planes:
+ *   T[n][h+2][ceil(c/32)][hi|lo][seg][32 ch][8 px], pixel x at index x+8 of its row, zero rows / pads around the image.
+ * virnet_chsplit writes T from an NHWC fp32 tensor (c % 4 == 0), applying lrelu(x*in_mul+in_add) (the forward conv's staging transform)
+ * and the hi/lo split of virnet_conv_f16 (bf16 != 0: one bf16 plane, single product); `out` holds virnet_chsplit_bytes() bytes.
+ * virnet_conv_wgrad_f16: dw[cout][cin][3][3] = sum_p dy[p][co] * a[p + tap][ci] from the two T tensors (cx / cy = their stored channels);
+ * the pixel range is split over workgroups whose partial sums go to `scratch` (virnet_conv_wgrad_f16_scratch_bytes() bytes, need not be
+ * zeroed) and are then reduced in a fixed order: dw is overwritten, and bitwise reproducible. */
+size_t virnet_chsplit_bytes(int n, int h, int w, int c);
+size_t virnet_conv_wgrad_f16_scratch_bytes(int n, int h, int w, int cx, int cy);
+size_t virnet_chsplit_colsum_bytes(int n, int h, int w, int c);
+/* db != NULL: the bias gradient as a by-product of the dY pass, db[ch] += sum over pixels of x[..][ch] for ch < cvalid (zero db first;
+ * replaces a virnet_colsum pass over the tensor); col_scratch = virnet_chsplit_colsum_bytes() bytes of per-block partial sums. */
+int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                   int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream);
+int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                          int bf16, void* stream);
 /* db[c] += sum over pixels of dy[p][c], c < cvalid (NHWC rows of `c` stored channels, c % 4 == 0); zero db first */
 int virnet_colsum(const float* dy, float* db, long npix, int c, int cvalid, void* stream);
 /* z[n][2h][2w][c] = dy at even positions, 0 elsewhere: the stride-2 conv's dgrad is a stride-1 conv of z (AttResUNet.py:67) */

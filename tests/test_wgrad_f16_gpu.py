@@ -1,0 +1,129 @@
+"""GPU parity of the f16-pipe weight gradient (csrc/wgrad_f16.hip; SURVEY.md 8-f1: backward of networks/AttResUNet.py:43,46 and
+DnCNN.py:22-29 under train_denoising_syn.py:176-179) against torch autograd on the CPU.
+
+  * virnet_chsplit: the channel-major fp16 hi/lo re-layout is reproduced element for element in numpy (bit-exact),
+  * virnet_conv_wgrad_f16 (+ the bias gradient fused into the dY pass): <= 2e-5 of the gradient's scale vs autograd (the split
+    operands carry 22 bits; fp32 accumulation in a different order), on shapes that exercise every strip / ring / group edge,
+  * bitwise reproducibility (no atomics), the bf16 single-product variant against autograd on bf16-rounded operands,
+  * ABI rejections."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from virnet_amd import _native as nat, ops
+from test_backward_gpu import autograd_conv, relerr
+from test_ops_gpu import nhwc, rnd
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _nseg(w):
+    return 8 * ((w + 63) // 64) + 2
+
+
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_chsplit_layout_is_exact(bf16):
+    n, h, w, c = 2, 6, 37, 40                                   # 40 channels: the second 32-block is a quarter full
+    x = rnd(n, c, h, w, seed=300)
+    mul, add = rnd(n, c, seed=301, lo=0.3, hi=1.2), rnd(n, c, seed=302)
+    lib = nat.load()
+    nbytes = lib.virnet_chsplit_bytes(n, h, w, c)
+    nseg, cb = _nseg(w), (c + 31) // 32
+    assert nbytes == n * (h + 2) * cb * 2 * nseg * 512
+    out = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+    xd, muld, addd = nhwc(x), mul.cuda(), add.cuda()            # (named: the launch must not outlive its operands)
+    nat.check(lib.virnet_chsplit(nat.ptr(xd), n, h, w, c, 1, 0.2, nat.ptr(muld), nat.ptr(addd), bf16, nat.ptr(out), None, None, 0,
+                                 nat.stream_handle()), "chsplit")
+    t = out.cpu().numpy().view(np.uint16).reshape(n, h + 2, cb, 2, nseg, 32, 8)
+    # the staging transform is one fused multiply-add per element (exact product, one rounding), then lrelu in fp32
+    a = F.leaky_relu((x.double() * mul.double().view(n, c, 1, 1) + add.double().view(n, c, 1, 1)).float(), 0.2)
+    if bf16:
+        hi = a.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+        planes = [hi]
+    else:
+        hi16 = a.to(torch.float16)
+        lo16 = (a - hi16.float()).to(torch.float16)
+        planes = [hi16.view(torch.int16).numpy().view(np.uint16), lo16.view(torch.int16).numpy().view(np.uint16)]
+    for p, ref in enumerate(planes):
+        exp = np.zeros((n, h + 2, cb * 32, nseg * 8), np.uint16)
+        exp[:, 1:h + 1, :c, 8:8 + w] = ref.transpose(0, 2, 1, 3)           # [n][row][ch][x], pixel x at index x + 8
+        got = t[:, :, :, p].transpose(0, 1, 2, 4, 3, 5).reshape(n, h + 2, cb * 32, nseg * 8)   # [n][row][cb][seg][32][8] -> [n][row][ch][x]
+        # -0.0 halves can appear where lrelu gives -0: compare as values there
+        same = (got == exp) | ((got & 0x7FFF) == 0) & ((exp & 0x7FFF) == 0)
+        assert same.all(), f"plane {p}: {int((~same).sum())} elements differ"
+
+
+SHAPES = [  # cin, cout, h, w, n
+    (96, 96, 5, 64, 1),        # minimum height the row ring takes; exactly one 64-pixel strip
+    (96, 96, 7, 65, 2),        # second strip one pixel wide
+    (32, 288, 6, 130, 1),      # nine output blocks = three groups; three strips
+    (288, 64, 9, 31, 2),       # two output blocks (8-wave workgroups), nine input blocks
+    (64, 16, 11, 50, 3),       # one output block (4-wave workgroups)
+    (160, 160, 6, 20, 1),      # five blocks: the second group is one short
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", SHAPES)
+def test_wgrad_f16_and_fused_bias_vs_autograd(cin, cout, h, w, n):
+    x, dy = rnd(n, cin, h, w, seed=310), rnd(n, cout, h, w, seed=311)
+    wt = rnd(cout, cin, 3, 3, seed=312) * 0.1
+    _, dw_ref, db_ref = autograd_conv(x, wt, torch.zeros(cout), dy, in_slope=0.2)
+    dw, db = ops.conv_wgrad(nhwc(x), nhwc(dy), (cout, cin, 3, 3), in_slope=0.2, bias_channels=cout)
+    assert relerr(dw.cpu(), dw_ref) <= TOL, relerr(dw.cpu(), dw_ref)
+    assert relerr(db.cpu(), db_ref) <= TOL, relerr(db.cpu(), db_ref)
+
+
+def test_wgrad_f16_is_bitwise_reproducible_and_close_to_the_fp32_kernel(monkeypatch):
+    cin = cout = 96
+    x, dy = rnd(4, cin, 24, 70, seed=320), rnd(4, cout, 24, 70, seed=321)
+    xd, dyd = nhwc(x), nhwc(dy)
+    a = ops.conv_wgrad(xd, dyd, (cout, cin, 3, 3), in_slope=0.2)
+    b = ops.conv_wgrad(xd, dyd, (cout, cin, 3, 3), in_slope=0.2)
+    assert torch.equal(a, b)                                     # fixed-order reduction, no atomics
+    monkeypatch.setenv("VIRNET_WGRAD_FORM", "f32")
+    c = ops.conv_wgrad(xd, dyd, (cout, cin, 3, 3), in_slope=0.2)
+    assert relerr(a.cpu(), c.cpu()) <= TOL
+
+
+def test_wgrad_f16_wide_dynamic_range():
+    """Gradients spanning five decades inside one contraction (the hi/lo split must carry the small ones next to the large)."""
+    g = torch.Generator().manual_seed(330)
+    cin, cout, h, w = 64, 96, 12, 48
+    x = rnd(2, cin, h, w, seed=331)
+    dy = rnd(2, cout, h, w, seed=332) * (10.0 ** torch.randint(-4, 1, (2, cout, h, w), generator=g).float())
+    wt = rnd(cout, cin, 3, 3, seed=333) * 0.1
+    _, dw_ref, _ = autograd_conv(x.double(), wt.double(), torch.zeros(cout).double(), dy.double())
+    dw = ops.conv_wgrad(nhwc(x), nhwc(dy), (cout, cin, 3, 3))
+    assert relerr(dw.cpu().double(), dw_ref) <= TOL
+
+
+def test_wgrad_bf16_variant_matches_bf16_rounded_autograd(monkeypatch):
+    monkeypatch.setenv("VIRNET_CONV_FORM", "bf16")
+    cin, cout, h, w, n = 96, 192, 10, 72, 2
+    x, dy = rnd(n, cin, h, w, seed=340), rnd(n, cout, h, w, seed=341)
+    a = F.leaky_relu(x, 0.2).to(torch.bfloat16).float()          # what virnet_chsplit(bf16) stores
+    dyr = dy.to(torch.bfloat16).float()
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(a, wt, None, padding=1).backward(dyr)               # products of bf16 values are exact in fp32: only the sum order differs
+    dw, db = ops.conv_wgrad(nhwc(x), nhwc(dy), (cout, cin, 3, 3), in_slope=0.2, bias_channels=cout)
+    assert relerr(dw.cpu(), wt.grad) <= TOL
+    assert relerr(db.cpu(), dy.sum((0, 2, 3))) <= TOL            # the bias gradient stays fp32
+
+
+def test_wgrad_f16_abi_rejects_bad_arguments():
+    lib = nat.load()
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    f = torch.zeros(1 << 16, dtype=torch.float32, device="cuda")
+    st = nat.stream_handle()
+    assert lib.virnet_chsplit(None, 1, 8, 8, 32, 0, 0.0, None, None, 0, nat.ptr(buf), None, None, 0, st) != 0
+    assert lib.virnet_chsplit(nat.ptr(f), 1, 8, 8, 30, 0, 0.0, None, None, 0, nat.ptr(buf), None, None, 0, st) != 0      # c % 4
+    assert lib.virnet_chsplit(nat.ptr(f), 1, 8, 8, 32, 0, 0.0, nat.ptr(f), None, 0, nat.ptr(buf), None, None, 0, st) != 0  # mul without add
+    assert lib.virnet_chsplit(nat.ptr(f), 1, 8, 8, 32, 0, 0.0, None, None, 0, nat.ptr(buf), None, nat.ptr(f), 8, st) != 0  # db without scratch
+    assert lib.virnet_conv_wgrad_f16(nat.ptr(buf), nat.ptr(buf), nat.ptr(f), nat.ptr(f), 1, 4, 8, 32, 32, 32, 32, 0, st) != 0   # h < 5
+    assert lib.virnet_conv_wgrad_f16(nat.ptr(buf), nat.ptr(buf), nat.ptr(f), nat.ptr(f), 1, 8, 8, 32, 32, 40, 32, 0, st) != 0   # cin > cx
+    assert lib.virnet_conv_wgrad_f16(nat.ptr(buf), nat.ptr(buf), None, nat.ptr(f), 1, 8, 8, 32, 32, 32, 32, 0, st) != 0
+    assert b"virnet_conv_wgrad_f16" in nat.last_error() if hasattr(nat, "last_error") else True

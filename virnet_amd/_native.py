@@ -102,6 +102,13 @@ SYMBOLS = [
     ("virnet_pack_thin_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv3x3_thin", C.c_int, [C.POINTER(ThinDesc), C.c_void_p]),
     ("virnet_conv_wgrad", C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    ("virnet_chsplit_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_conv_wgrad_f16_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_chsplit_colsum_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_chsplit", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("virnet_conv_wgrad_f16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]),
     ("virnet_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_zero_stuff2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_space_to_depth2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -1,0 +1,558 @@
+// wgrad_f16.hip -- weight gradient of the stride-1 3x3 convolutions on the f16 matrix pipe (training step, SURVEY.md 8-f1:
+// the backward of networks/AttResUNet.py:43,46,117,139 and networks/DnCNN.py:22-29, train_denoising_syn.py:176-179).
+//
+//   dW[co][ci][ky][kx] = sum over pixels p of dY[p][co] * A[p + (ky-1, kx-1)][ci]          (A = the forward conv's staged input)
+// contracts over PIXELS, so an MFMA k-step is 16 consecutive pixels of a row and both operands must be CHANNEL-major (8 consecutive
+// pixels of one channel per lane), the transpose of the NHWC tensors the rest of the path uses.  Two kernels:
+//   1. chsplit_kernel: NHWC fp32 -> channel-major fp16 planes T[n][h+2][c/32][hi|lo][seg][32 ch][8 px] (pixel x at index x+8, one
+//      zero row above and below, zero pads left and right), applying the forward conv's staging transform (lrelu(x*mul+add)) and the
+//      hi/lo split of conv_f16.hip on the way (bf16 variant: one bf16 plane).  Bandwidth-bound; the transpose goes through LDS.
+//   2. conv_wgrad_f16_kernel: workgroup = NWV waves = NWV output-channel blocks x ONE input-channel block, each wave keeping all nine
+//      taps of its (co, ci) pair in registers (144 accumulator VGPRs).  A tile = one image row x 64 pixels: the dY segments and the
+//      three A rows (with their 8-pixel aprons) are contiguous runs of T and come in by LDS-DMA with NO staging arithmetic;
+//      LDS image [seg][32 ch][16 B] -> conflict-free ds_read_b128 fragments.  The kx = 0 / 2 taps are the aligned window shifted by
+//      one pixel = 2 bytes: v_alignbyte over the window's 4 + 2 dwords.  Three products per k-step as in conv_f16.hip (bf16: one).
+//      Tiles are split across workgroups (split-K); partial sums are added to dW with fp32 atomics (dW zeroed by the caller).
+// Accuracy: as conv_f16.hip for operands above fp16's subnormal range; gradients far below 6e-5 in magnitude lose relative precision
+// (absolute error <= 3e-8 per element) -- DESIGN.md 7.
+#include "conv_f16_common.h"
+#include <cstdlib>
+
+namespace {
+using namespace virnet;
+
+struct TGeom {
+  int n, h, w, c;      // source tensor (c = stored channels)
+  int cb;              // 32-channel blocks of T
+  int nseg;            // 8-pixel segments per row of T
+};
+
+__host__ __device__ inline int t_nseg(int w) { return 8 * ((w + 63) / 64) + 2; }
+
+// ---- 1. NHWC fp32 -> T -------------------------------------------------------------------------------------------------------------
+// block = (image, padded row, channel block, group of 8 segments); 256 threads
+template <int BF>
+__global__ __launch_bounds__(256) void chsplit_kernel(const float* __restrict__ x, const float* __restrict__ in_mul, const float* __restrict__ in_add,
+                                                      int in_act, float in_slope, TGeom g, unsigned short* __restrict__ out,
+                                                      float* __restrict__ colpart) {
+  __shared__ unsigned short tile[2][64][34];             // [plane][T index in group][channel (+2 pad)]
+  __shared__ float red[32][33];                          // per-pixel-thread channel sums (bias gradient by-product)
+  const int sgs = (g.nseg + 7) / 8;
+  int b = blockIdx.x;
+  const int sg = b % sgs; b /= sgs;
+  const int cb = b % g.cb; b /= g.cb;
+  const int prow = b % (g.h + 2);
+  const int img = b / (g.h + 2);
+  const int tid = threadIdx.x;
+  const int q = tid & 7;                                 // channel quad
+  const int c0 = cb * 32 + q * 4;
+  const float slope = in_act ? in_slope : 1.f;
+  f32x4 m4 = f32x4{1.f, 1.f, 1.f, 1.f}, a4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (in_mul && c0 < g.c) {
+    m4 = *reinterpret_cast<const f32x4*>(in_mul + (size_t)img * g.c + c0);
+    a4 = *reinterpret_cast<const f32x4*>(in_add + (size_t)img * g.c + c0);
+  }
+  f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ti = it * 32 + (tid >> 3);                 // T index inside the group
+    const int px = sg * 64 + ti - 8;
+    const bool ok = prow >= 1 && prow <= g.h && px >= 0 && px < g.w && c0 < g.c;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + (prow - 1)) * g.w + px) * g.c + c0);
+      v = lrelu4(v * m4 + a4, slope);
+    }
+    csum += v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (BF) {
+        const __bf16 hb = (__bf16)v[e];
+        tile[0][ti][q * 4 + e] = __builtin_bit_cast(unsigned short, hb);
+      } else {
+        const _Float16 hi = (_Float16)v[e];
+        const _Float16 lo = (_Float16)(v[e] - (float)hi);
+        tile[0][ti][q * 4 + e] = __builtin_bit_cast(unsigned short, hi);
+        tile[1][ti][q * 4 + e] = __builtin_bit_cast(unsigned short, lo);
+      }
+    }
+  }
+  if (colpart) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid >> 3][q * 4 + e] = csum[e];
+  }
+  __syncthreads();
+  if (colpart && tid < 32) {                             // this block's sum over its 64 pixels, per channel: plain store, reduced later
+    float t = 0.f;
+#pragma unroll 8
+    for (int p2 = 0; p2 < 32; ++p2) t += red[p2][tid];
+    const size_t nblk = (size_t)g.n * (g.h + 2) * sgs;
+    const size_t blk = ((size_t)img * (g.h + 2) + prow) * sgs + sg;
+    colpart[((size_t)cb * nblk + blk) * 32 + tid] = t;
+  }
+  const int seg = tid >> 5, ch = tid & 31;               // 8 segments x 32 channels
+  const int gseg = sg * 8 + seg;
+  if (gseg < g.nseg) {
+#pragma unroll
+    for (int plane = 0; plane < (BF ? 1 : 2); ++plane) {
+      unsigned short v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[plane][seg * 8 + e][ch];
+      u32x4 pk = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16), (unsigned)v[4] | ((unsigned)v[5] << 16),
+                       (unsigned)v[6] | ((unsigned)v[7] << 16)};
+      const size_t o = ((((size_t)img * (g.h + 2) + prow) * g.cb + cb) * 2 + plane) * g.nseg + gseg;
+      *reinterpret_cast<u32x4*>(out + (o * 32 + ch) * 8) = pk;
+    }
+  }
+}
+
+// db[cb*32 + ch] += sum over blocks of colpart[cb][blk][ch]; grid (cb, slices)
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, long nblk, int cvalid) {
+  __shared__ float red[8][32];
+  const int cb = blockIdx.x, j = threadIdx.x >> 5, ch = threadIdx.x & 31;
+  float t = 0.f;
+  for (long blk = (long)blockIdx.y * 8 + j; blk < nblk; blk += (long)gridDim.y * 8) t += part[((size_t)cb * nblk + blk) * 32 + ch];
+  red[j][ch] = t;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u += red[k][threadIdx.x];
+    const int c = cb * 32 + threadIdx.x;
+    if (c < cvalid) atomicAdd(db + c, u);
+  }
+}
+
+// ---- 2. the GEMM ----------------------------------------------------------------------------------------------------------------
+struct GArgs {
+  const char* xt;   // T of the forward input   [n][h+2][ncib][2][nseg][32][8] fp16
+  const char* yt;   // T of the output gradient [n][h+2][ncob][2][nseg][32][8]
+  float* dw;        // partial sums part[run][9][ncob*32][ncib*32] (every element written: no zeroing, no atomics)
+  int n, h, w, nseg;
+  int cin, cout, ncib, ncob;
+  int nsteps, nxs, nsplit, npairs, run;
+  long long* tlog;    // -DVIRNET_F16_TIMING builds: per-workgroup cycle sums (tools/wgrad_timeline.py)
+};
+
+// Workgroup = NWV output-channel blocks x KG k-steps = KG*NWV waves (twelve for the 96/192/288-channel layers: exactly three per
+// SIMD -- two six-wave workgroups per CU left most CUs with a 2/3/3/4 split), ONE input-channel block, one workgroup per CU.
+// A step = one image row x 16*KG pixels, one MFMA k-step of 16 pixels per wave.  Steps walk DOWN a column strip, so of the three A
+// rows a step reads only one is new.  Operands arrive by LDS-DMA DIST steps ahead of their use (a DMA round trip is ~3 us, a step
+// ~1.5-2 us): a ring of DIST+5 A-row slots and DIST+1 dY stages; every wave issues the SAME number of 1-KB pieces per step so the wait
+// before a step is a literal `s_waitcnt vmcnt(pieces of the later steps)` and never drains the prefetch.  168 registers per wave.
+template <int BF, int KG> struct WgCfg {
+  static constexpr int NPL = BF ? 1 : 2;
+  static constexpr int DIST = BF ? 4 : 2;
+  static constexpr int RING = DIST + 5, STAGES = DIST + 1;
+  static constexpr int XPL = (2 * KG + 2) * 512, XROW = NPL * XPL;   // one A row: [plane][seg 2KG+2][32 ch][16 B]
+  static constexpr int YPL = 2 * KG * 512, YW = NPL * YPL;          // dY of one channel block: [plane][seg 2KG][32 ch][16 B]
+  static constexpr int lds(int nwv) { return RING * XROW + STAGES * nwv * YW; }
+};
+
+// a wave-uniform pointer, pinned to scalar registers so that `p + lane offset` takes the saddr + 32-bit voffset form (one VGPR)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+  return reinterpret_cast<const char*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+#ifdef VIRNET_F16_TIMING
+#define WT_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#define WT_ADD(var, t0v) do { const long long n_ = WT_NOW(); var += n_ - (t0v); (t0v) = n_; } while (0)
+#else
+#define WT_NOW() 0ll
+#define WT_ADD(var, t0v) do { } while (0)
+#endif
+
+template <int NWV, int BF, int KG>
+__global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_wgrad_f16_kernel(const GArgs a) {
+  using Cfg = WgCfg<BF, KG>;
+  constexpr int NW = KG * NWV, NPL = Cfg::NPL, DIST = Cfg::DIST, RING = Cfg::RING, STAGES = Cfg::STAGES;
+  constexpr int XPL = Cfg::XPL, XROW = Cfg::XROW, YPL = Cfg::YPL, YW = Cfg::YW, YST = NWV * YW;
+  constexpr int XQ = KG + 1;                             // 1-KB pieces (two segments) of one plane of an A row
+  constexpr int NYQ = NWV * NPL * KG;                    // dY pieces of a step
+  constexpr int NRQ = NPL * XQ + NYQ, NFQ = NPL * 3 * XQ + NYQ;   // pieces of a normal step / of the first step of a strip
+  constexpr int PN = (NRQ + NW - 1) / NW, PF = (NFQ + NW - 1) / NW;   // ... per wave (the round-up repeats a piece)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xs = smem;                                 // RING row slots
+  char* const ys = smem + RING * XROW;                   // STAGES stages
+
+  // workgroups that walk the same steps (same run, every (co group, ci block) pair) are made neighbours on ONE XCD, so the tiles they
+  // share come from that XCD's L2 after the first reader: hardware block id -> XCD = id % 8
+  const int total = a.npairs * a.nsplit;
+  const int xcd = blockIdx.x & 7, q8 = total >> 3, r8 = total & 7;
+  const int vid = xcd * q8 + min(xcd, r8) + (blockIdx.x >> 3);   // XCD x holds the virtual ids [x*q8 + min(x, r8), ...) in dispatch order
+  const int pair = vid % a.npairs;                       // (co group, ci block)
+  const int runi = vid / a.npairs;
+  const int cgrp = pair / a.ncib, cib = pair - cgrp * a.ncib;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wv % NWV, kg = wv / NWV;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const unsigned lane16 = lane * 16;
+  const int cob = cgrp * NWV + cw;
+  const bool active = cob < a.ncob;
+  const size_t plx = (size_t)a.nseg * 512, rowx = (size_t)a.ncib * 2 * plx, rowy = (size_t)a.ncob * 2 * plx;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  [[maybe_unused]] long long tw = 0, ti = 0, tc = 0, tmark = WT_NOW();
+  [[maybe_unused]] const long long tstart = tmark;
+  const int t0 = runi * a.run, t1 = min(t0 + a.run, a.nsteps);
+  if (t0 < t1) {
+    // issue cursor (the step whose operands are requested next) and consume cursor (the step computed next)
+    int iu = t0, iy = t0 % a.h, istrip = t0 / a.h, icnt = 0;
+    int cy = iy, ccnt = 0;                               // ccnt: ring position of the consumed step's first row
+
+    // Row pointers of the issue cursor (wave-uniform): A row iy of this ci block / dY row iy of the group's first block, at the strip's
+    // first segment.  They advance by one row per step; only a strip change recomputes them.
+    const char* xrow = nullptr;
+    const char* yrow = nullptr;
+    auto seek = [&]() {
+      const int img = istrip / a.nxs, xsi = istrip - img * a.nxs;
+      xrow = uniform_ptr(a.xt + ((size_t)img * (a.h + 2) + iy) * rowx + (size_t)cib * 2 * plx + (size_t)xsi * 2 * KG * 512);
+      yrow = uniform_ptr(a.yt + ((size_t)img * (a.h + 2) + iy + 1) * rowy + (size_t)(xsi * 2 * KG + 1) * 512);
+    };
+    seek();
+    // The pieces this wave issues on a NORMAL step never change (piece q = i * NW + wv): decode them once.
+    unsigned nsrc[PN], ndst[PN];                         // source offset from xrow + 2 rows / yrow; LDS offset inside the slot / stage
+    bool nisx[PN];
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+      int q = i * NW + wv;
+      if (q >= NRQ) q -= NYQ;                            // round-up: repeat a dY piece
+      nisx[i] = q < NPL * XQ;
+      if (nisx[i]) {
+        const int plane = q / XQ, s2 = q - plane * XQ;
+        nsrc[i] = (unsigned)(plane * plx + s2 * 1024);
+        ndst[i] = plane * XPL + s2 * 1024;
+      } else {
+        const int qy = q - NPL * XQ;
+        const int w2 = qy / (NPL * KG), rem = qy - w2 * (NPL * KG), plane = rem / KG, s2 = rem - plane * KG;
+        const int cb2 = min(cgrp * NWV + w2, a.ncob - 1);
+        nsrc[i] = (unsigned)(((size_t)cb2 * 2 + plane) * plx + s2 * 1024);
+        ndst[i] = RING * XROW + w2 * YW + plane * YPL + s2 * 1024;
+      }
+    }
+
+    // requests the operands of step `iu`; every wave issues exactly PF (first step of a strip / of the run) or PN pieces
+    auto issue = [&](bool run_start) -> bool {
+      const bool first = run_start || iy == 0;
+      const unsigned ystage = ((iu - t0) % STAGES) * YST;
+      if (!first) {
+        // the common case: one new A row (padded row iy + 2) + the step's dY; a handful of scalar instructions per piece
+        const char* const xnew = xrow + 2 * rowx;
+        const unsigned xslot = (icnt % RING) * XROW;
+#pragma unroll
+        for (int i = 0; i < PN; ++i) {
+          const char* const src = (nisx[i] ? xnew : yrow) + nsrc[i];
+          const unsigned dst = ndst[i] + (nisx[i] ? xslot : ystage);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane16),
+                                           (__attribute__((address_space(3))) void*)(smem + dst), 16, 0, 0);
+        }
+        icnt += 1;
+      } else {
+        char* const ydst = ys + ystage;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          int q = i * NW + wv;
+          if (q >= NFQ) q -= NYQ;                        // round-up: repeat a dY piece
+          if (q < NPL * 3 * XQ) {
+            const int rr = q / (NPL * XQ), rem = q - rr * (NPL * XQ), plane = rem / XQ, s2 = rem - plane * XQ;
+            const int slot = (icnt + rr) % RING;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_ptr(xrow + (size_t)rr * rowx + plane * plx + s2 * 1024) + lane16),
+                                             (__attribute__((address_space(3))) void*)(xs + slot * XROW + plane * XPL + s2 * 1024), 16, 0, 0);
+          } else {
+            const int qy = q - NPL * 3 * XQ;
+            const int w2 = qy / (NPL * KG), rem = qy - w2 * (NPL * KG), plane = rem / KG, s2 = rem - plane * KG;
+            const int cb2 = min(cgrp * NWV + w2, a.ncob - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uniform_ptr(yrow + ((size_t)cb2 * 2 + plane) * plx + s2 * 1024) + lane16),
+                                             (__attribute__((address_space(3))) void*)(ydst + w2 * YW + plane * YPL + s2 * 1024), 16, 0, 0);
+          }
+        }
+        icnt += 3;
+      }
+      ++iu; ++iy;
+      xrow += rowx; yrow += rowy;
+      if (iy == a.h) { iy = 0; ++istrip; if (iu < t1) seek(); }
+      return first;
+    };
+
+    // prologue: steps t0 .. t0+DIST-1 requested; pend = pieces of the steps AFTER the one about to be computed, oldest first
+    bool pf[DIST];                                        // was step (t + 1 + j) a first-of-strip request?
+#pragma unroll
+    for (int j = 0; j < DIST; ++j) pf[j] = false;
+    int ahead = 0;                                        // requested steps beyond the current one
+    issue(true);                                          // step t0 (always `first`)
+#pragma unroll
+    for (int j = 0; j < DIST - 1; ++j)
+      if (iu < t1) { pf[j] = issue(false); ++ahead; }
+
+    WT_ADD(ti, tmark);
+#pragma clang loop unroll(disable)
+    for (int t = t0; t < t1; ++t) {
+      // wait for step t's operands: the pieces of the `ahead` later steps may stay in flight
+      {
+        bool anyf = false;
+#pragma unroll
+        for (int j = 0; j < DIST - 1; ++j) anyf |= pf[j];
+#ifdef WG_NOWAIT
+        if (t + 1 < t1) wait_vm_barrier<63>(); else wait_vm_barrier<0>();
+#else
+        if (ahead == DIST - 1 && !anyf) wait_vm_barrier<(DIST - 1) * PN>();
+        else wait_vm_barrier<0>();
+#endif
+      }
+      WT_ADD(tw, tmark);
+      // every wave is past step t-1: its slots are free for the request DIST-1 steps ahead
+#pragma unroll
+      for (int j = 0; j + 1 < DIST - 1; ++j) pf[j] = pf[j + 1];
+#ifdef WG_NODMA
+      if (iu < t1 && a.n < 0) { pf[DIST - 2] = issue(false); } else { pf[DIST - 2] = false; --ahead; }
+#else
+      if (iu < t1) { pf[DIST - 2] = issue(false); } else { pf[DIST - 2] = false; --ahead; }
+#endif
+#ifdef WG_NOMFMA
+      if (active && a.n < 0) {
+#else
+      if (active) {
+#endif
+        // one lane-dependent LDS offset for both operands; everything else is a scalar (slot / stage / plane) plus an immediate
+        // (lane16 = lhi * 512 + l31 * 16 is also this lane's fragment offset inside a row / dY image; the k-step adds kg * 1024.)
+        // The scalar parts are re-derived per read (opaque to CSE): hoisted per-row addresses would cost seven live registers.
+        const unsigned ybs = RING * XROW + ((t - t0) % STAGES) * YST + cw * YW + kg * 1024;
+        // operand-major phases keep ONE dY fragment and one window live at a time (144 accumulators + ~20 registers: three
+        // waves per SIMD): dy_lo * a_hi, dy_hi * a_hi, dy_hi * a_lo  (bf16: the single product)
+#pragma unroll
+        for (int ph = 0; ph < (BF ? 1 : 3); ++ph) {
+          const int plane = ph == 2 ? 1 : 0;
+          unsigned so_y = ybs + ((!BF && ph == 0) ? YPL : 0);
+          asm volatile("" : "+s"(so_y));
+#ifdef WG_NOLDS
+          h8 af = __builtin_bit_cast(h8, u32x4{lane16, lane16 + 1, lane16 + 2, lane16 + 3});
+          if (a.n < 0) af = *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
+#else
+          const h8 af = *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
+#endif
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            // window of this k-step: segment 1 + 2kg + lhi of the row; xb points ONE segment earlier so that the three reads
+            // (last dword of the previous segment, the segment, first dword of the next) use non-negative immediates
+            unsigned so_x = ((ccnt + r) % RING) * XROW + plane * XPL + kg * 1024;
+            asm volatile("" : "+s"(so_x));
+            const char* const xb = smem + (lane16 + so_x);
+#ifdef WG_NOLDS
+            u32x4 d = u32x4{so_x, so_x + 1, lane16, lane16 + 7};
+            unsigned dm = so_x + 5, dp = so_x + 9;
+            if (a.n < 0) {
+              d = *reinterpret_cast<const u32x4*>(xb + 512);
+              dm = *reinterpret_cast<const unsigned*>(xb + 12);
+              dp = *reinterpret_cast<const unsigned*>(xb + 1024);
+            }
+#else
+            const u32x4 d = *reinterpret_cast<const u32x4*>(xb + 512);
+            const unsigned dm = *reinterpret_cast<const unsigned*>(xb + 12);
+            const unsigned dp = *reinterpret_cast<const unsigned*>(xb + 1024);
+#endif
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+              u32x4 f = d;
+              if (dx == 0)
+                f = u32x4{__builtin_amdgcn_alignbyte(d.x, dm, 2), __builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2),
+                          __builtin_amdgcn_alignbyte(d.w, d.z, 2)};
+              if (dx == 2)
+                f = u32x4{__builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2), __builtin_amdgcn_alignbyte(d.w, d.z, 2),
+                          __builtin_amdgcn_alignbyte(dp, d.w, 2)};
+              if (BF)
+                acc[r * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af), __builtin_bit_cast(b8, f), acc[r * 3 + dx], 0, 0, 0);
+              else
+                acc[r * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(h8, f), acc[r * 3 + dx], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the next window's reads behind these MFMAs (register budget)
+          }
+        }
+      }
+      WT_ADD(tc, tmark);
+      ++ccnt; ++cy;
+      if (cy == a.h) { cy = 0; ccnt += 2; }              // the next step starts a strip: its request brought three new rows, not one
+    }
+  }
+
+  // ---- epilogue: the KG k-step waves of a channel block are summed through LDS (three taps at a time), then the partial sums of this
+  // (run, pair) go to the scratch tensor part[run][tap][co][ci] with plain coalesced stores (lane = ci): no atomics, bitwise reproducible
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(smem) + cw * (3 * 16 * 64);
+#pragma unroll 1
+  for (int kk = 1; kk < KG; ++kk) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (kg == kk) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[c * 3 + j][r];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[c * 3 + j][r] += red[(j * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && tid == 0) {
+    long long* o = a.tlog + (size_t)blockIdx.x * 8;
+    o[0] = tstart; o[1] = tw; o[2] = ti; o[3] = tc; o[4] = WT_NOW(); o[5] = t1 - t0;
+  }
+  if (a.tlog && lane == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    atomicOr(reinterpret_cast<unsigned long long*>(a.tlog + (size_t)blockIdx.x * 8 + 6), (unsigned long long)(((hw >> 4) & 3) + 1) << (4 * wv));
+    if (wv == 0) a.tlog[(size_t)blockIdx.x * 8 + 7] = ((long long)(xcc & 0xf) << 16) | (hw & 0xffff);
+  }
+#endif
+  if (!active || kg != 0) return;
+  // D[i = co][j = ci]: lane = ci (l31), register r -> co = (r&3) + 8*(r>>2) + 4*lhi
+  const int cop = a.ncob * 32, cip = a.ncib * 32;
+  float* const part = a.dw + (size_t)runi * 9 * cop * cip + (size_t)(cob * 32 + 4 * lhi) * cip + cib * 32 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((size_t)t * cop + (r & 3) + 8 * (r >> 2)) * cip] = acc[t][r];
+}
+
+// dw[co][ci][t] = sum over runs of part[run][t][co][ci]   (thread = one (t, co, ci); consecutive threads = consecutive ci)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int per = 9 * cop * cip;
+  if (i >= per) return;
+  const int ci = i % cip, co = (i / cip) % cop, t = i / (cip * cop);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 4 <= nrun; r += 4) {
+    s0 += part[(size_t)r * per + i];
+    s1 += part[(size_t)(r + 1) * per + i];
+    s2 += part[(size_t)(r + 2) * per + i];
+    s3 += part[(size_t)(r + 3) * per + i];
+  }
+  for (; r < nrun; ++r) s0 += part[(size_t)r * per + i];
+  if (co < cout && ci < cin) dw[((size_t)co * cin + ci) * 9 + t] = (s0 + s1) + (s2 + s3);
+}
+
+constexpr int kKG = 4;                                    // k-steps (waves) per channel block: 64-pixel steps
+struct Plan { int nwv, pairs, split, run, nxs, nsteps; };
+inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
+  Plan p;
+  p.nwv = ncob >= 3 ? 3 : ncob;
+  p.nxs = (w + 16 * kKG - 1) / (16 * kKG);
+  p.nsteps = n * p.nxs * h;
+  const int groups = (ncob + p.nwv - 1) / p.nwv;
+  p.pairs = groups * ncib;
+  int split = 256 / p.pairs;                             // one workgroup per CU (its LDS rings take most of the 160 KB)
+  if (split > p.nsteps / 4) split = p.nsteps / 4;        // runs of at least four steps (each run primes three rows)
+  if (split < 1) split = 1;
+  p.run = (p.nsteps + split - 1) / split;
+  p.split = split;
+  return p;
+}
+
+template <int NWV, int BF>
+int launch_g(GArgs k, hipStream_t st) {
+  constexpr int KG = kKG;
+  constexpr int LDS = WgCfg<BF, KG>::lds(NWV) > 3 * 16 * 64 * 4 * NWV ? WgCfg<BF, KG>::lds(NWV) : 3 * 16 * 64 * 4 * NWV;   // K loop / epilogue exchange
+  static unsigned long long attr_done = 0;
+  auto kern = conv_wgrad_f16_kernel<NWV, BF, KG>;
+  if (virnet::first_use_on_device(attr_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wgrad_f16): %s", hipGetErrorString(e));
+  }
+  const Plan p = make_plan(k.n, k.h, k.w, k.ncob, k.ncib);
+  k.nxs = p.nxs; k.nsteps = p.nsteps; k.run = p.run; k.nsplit = p.split; k.npairs = p.pairs;
+  hipLaunchKernelGGL(kern, dim3(p.pairs * p.split), dim3(64 * KG * NWV), LDS, st, k);
+  return virnet::check_launch("conv_wgrad_f16 launch");
+}
+
+static long long* g_wlog = nullptr;
+}  // namespace
+
+#ifdef VIRNET_F16_TIMING
+extern "C" void virnet_debug_wgrad_timing_buffer(void* p) { g_wlog = static_cast<long long*>(p); }
+#endif
+
+extern "C" size_t virnet_chsplit_bytes(int n, int h, int w, int c) {
+  return (size_t)n * (h + 2) * ((c + 31) / 32) * 2 * t_nseg(w) * 512;
+}
+
+extern "C" size_t virnet_chsplit_colsum_bytes(int n, int h, int w, int c) {
+  return (size_t)n * (h + 2) * ((t_nseg(w) + 7) / 8) * ((c + 31) / 32) * 32 * sizeof(float);
+}
+
+extern "C" int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                              int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream) {
+  VIRNET_REQUIRE(x && out, "virnet_chsplit: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "virnet_chsplit: bad shape n=%d h=%d w=%d c=%d (c %% 4 == 0)", n, h, w, c);
+  VIRNET_REQUIRE((in_mul == nullptr) == (in_add == nullptr), "virnet_chsplit: in_mul and in_add go together");
+  VIRNET_REQUIRE(!in_act || (in_slope >= 0.f && in_slope <= 1.f), "virnet_chsplit: in_slope=%g outside [0,1]", in_slope);
+  VIRNET_REQUIRE(!db || (col_scratch && cvalid >= 1 && cvalid <= c), "virnet_chsplit: db needs col_scratch and 1 <= cvalid=%d <= c=%d", cvalid, c);
+  TGeom g{n, h, w, c, (c + 31) / 32, t_nseg(w)};
+  const int sgs = (g.nseg + 7) / 8;
+  const long blocks = (long)n * (h + 2) * g.cb * sgs;
+  VIRNET_REQUIRE(blocks < (1L << 31), "virnet_chsplit: tensor too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* const cp = db ? col_scratch : nullptr;
+  if (bf16)
+    hipLaunchKernelGGL(chsplit_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, x, in_mul, in_add, in_act, in_slope, g, static_cast<unsigned short*>(out), cp);
+  else
+    hipLaunchKernelGGL(chsplit_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, x, in_mul, in_add, in_act, in_slope, g, static_cast<unsigned short*>(out), cp);
+  if (int rc = virnet::check_launch("chsplit launch")) return rc;
+  if (db) {
+    const long nblk = (long)n * (h + 2) * sgs;
+    const int slices = (int)(nblk / 64 < 1 ? 1 : nblk / 64 > 64 ? 64 : nblk / 64);
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3(g.cb, slices), dim3(256), 0, st, col_scratch, db, nblk, cvalid);
+    return virnet::check_launch("colpart_reduce launch");
+  }
+  return 0;
+}
+
+extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                                     int bf16, void* stream) {
+  VIRNET_REQUIRE(xt && yt && dw && scratch, "virnet_conv_wgrad_f16: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && h > 4 && w > 0, "virnet_conv_wgrad_f16: h=%d (the row ring needs h >= 5) or empty input", h);
+  VIRNET_REQUIRE(cin >= 1 && cin <= cx && cout >= 1 && cout <= cy, "virnet_conv_wgrad_f16: cin=%d / cout=%d beyond the stored %d / %d channels", cin, cout, cx, cy);
+  GArgs k{};
+  k.xt = static_cast<const char*>(xt); k.yt = static_cast<const char*>(yt); k.dw = scratch;
+  k.n = n; k.h = h; k.w = w; k.nseg = t_nseg(w);
+  k.cin = cin; k.cout = cout;
+  k.tlog = g_wlog;
+  k.ncib = (cx + 31) / 32; k.ncob = (cy + 31) / 32;     // blocks of the T tensors (all stored channels)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GArgs kk = k;
+  const Plan p = make_plan(n, h, w, kk.ncob, kk.ncib);
+  const int nwv = p.nwv;
+  int rc;
+  if (bf16) rc = nwv == 3 ? launch_g<3, 1>(kk, st) : nwv == 2 ? launch_g<2, 1>(kk, st) : launch_g<1, 1>(kk, st);
+  else rc = nwv == 3 ? launch_g<3, 0>(kk, st) : nwv == 2 ? launch_g<2, 0>(kk, st) : launch_g<1, 0>(kk, st);
+  if (rc) return rc;
+  const int cop = kk.ncob * 32, cip = kk.ncib * 32;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * cop * cip + 255) / 256), dim3(256), 0, st, scratch, dw, p.split, cop, cip, cout, cin);
+  return virnet::check_launch("wgrad_reduce launch");
+}
+
+extern "C" size_t virnet_conv_wgrad_f16_scratch_bytes(int n, int h, int w, int cx, int cy) {
+  const int ncib = (cx + 31) / 32, ncob = (cy + 31) / 32;
+  const Plan p = make_plan(n, h, w, ncob, ncib);
+  return (size_t)p.split * 9 * ncob * 32 * ncib * 32 * sizeof(float);
+}

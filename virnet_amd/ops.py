@@ -6,6 +6,7 @@ returned maps are NCHW like the reference's.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -516,9 +517,12 @@ def sft_apply(raw: Tensor, rec: Tensor, chan0: int, nchan: int, step: int, att) 
 # training step: weight / bias gradients and the layout helpers of the input-gradient convs
 # ----------------------------------------------------------------------------------------------------------------------
 def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: int = 1, transposed: bool = False,
-               in_slope: Optional[float] = None, in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None) -> Tensor:
+               in_slope: Optional[float] = None, in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None,
+               bias_channels: Optional[int] = None):
     """Weight gradient in the reference layout (OIHW, or IOHW 2x2 for the transposed conv) from NHWC forward input ``x`` and
-    NHWC output gradient ``dy`` (for the transposed conv: the space-to-depth gradient)."""
+    NHWC output gradient ``dy`` (for the transposed conv: the space-to-depth gradient).  With ``bias_channels`` the bias gradient
+    (sum of ``dy`` over pixels, first ``bias_channels`` channels) is returned too -- ``(dw, db)`` -- fused into the f16 path's pass
+    over ``dy`` where that path runs, a ``virnet_colsum`` launch otherwise."""
     _dev_check(x, "x"); _dev_check(dy, "dy")
     n, h, w, cx = x.shape
     cy = dy.shape[3]
@@ -527,6 +531,11 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     else:
         cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
     dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
+    form = conv_form()
+    if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16")
+            and os.environ.get("VIRNET_WGRAD_FORM", "f16") != "f32"):
+        return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
+                               bias_channels=bias_channels)
     rows = 4 * cout if transposed else cout
     ctr = torch.zeros(((rows + 31) // 32) * ((cin + 31) // 32), dtype=torch.int32, device=x.device)
     d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw),
@@ -542,7 +551,54 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
         e1.record()
         pix = n * (h // stride) * (w // stride)
         _TIMER.records.append((("wgrad", ks, stride, int(transposed)), 2.0 * pix * cin * cout * (4 if transposed else ks * ks), e0, e1))
+    if bias_channels is not None:
+        return dw, colsum(dy, bias_channels)
     return dw
+
+
+_WORKSPACES: dict = {}
+
+
+def _workspace(tag: str, nbytes: int, device: torch.device) -> Tensor:
+    """Grow-only scratch buffer per (device, stream, tag).  Launches on one stream are ordered, so consecutive users of the same
+    buffer cannot overlap; going through the caching allocator for three ~200 MB blocks per weight gradient instead cost whole
+    steps of hipMalloc stalls while its pools warmed up."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) if buf is not None else nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_slope, in_mul, in_add, *, bf16: bool,
+                    bias_channels: Optional[int] = None):
+    """Stride-1 3x3 weight gradient on the f16 pipe (csrc/wgrad_f16.hip): both operands are first re-laid channel-major as fp16
+    hi/lo planes (``virnet_chsplit``, which also applies the forward conv's staging transform to ``x``), then contracted over pixels."""
+    lib = nat.load()
+    n, h, w, cx = x.shape
+    cy = dy.shape[3]
+    st = nat.stream_handle()
+    xt = _workspace("wgrad_xt", lib.virnet_chsplit_bytes(n, h, w, cx), x.device)
+    yt = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, h, w, cy), x.device)
+    timed = _TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    nat.check(lib.virnet_chsplit(nat.ptr(x), n, h, w, cx, int(in_slope is not None), 0.0 if in_slope is None else in_slope,
+                                 nat.ptr(in_mul), nat.ptr(in_add), int(bf16), nat.ptr(xt), None, None, 0, st), "chsplit")
+    db = col = None
+    if bias_channels is not None:
+        db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
+        col = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, h, w, cy), x.device)
+    nat.check(lib.virnet_chsplit(nat.ptr(dy), n, h, w, cy, 0, 0.0, None, None, int(bf16), nat.ptr(yt), nat.ptr(col), nat.ptr(db),
+                                 0 if bias_channels is None else bias_channels, st), "chsplit")
+    scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_scratch_bytes(n, h, w, cx, cy), x.device)
+    nat.check(lib.virnet_conv_wgrad_f16(nat.ptr(xt), nat.ptr(yt), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16), st), "conv_wgrad_f16")
+    if timed:
+        e1.record()
+        _TIMER.records.append((("wgrad_f16", 3, 1, 0), 2.0 * n * h * w * cin * cout * 9, e0, e1))
+    return dw if bias_channels is None else (dw, db)
 
 
 def colsum(dy: Tensor, cvalid: Optional[int] = None) -> Tensor:

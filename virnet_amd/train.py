@@ -110,23 +110,28 @@ def _side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
     return _SIDE[idx]
 
 
+def _wgrad_pair(conv, x_in: Tensor, dy: Tensor, stride: int, in_slope: Optional[float], cvalid: Optional[int]) -> Dict:
+    """{weight: dW[, bias: db]} of one conv; the bias gradient rides on the weight-gradient's pass over dy where it can."""
+    if conv.bias is None:
+        return {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
+    dw, db = ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope,
+                            bias_channels=conv.cout if cvalid is None else cvalid)
+    return {conv.weight: dw, conv.bias: db}
+
+
 def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1, in_slope: Optional[float] = None,
                 cvalid: Optional[int] = None, reducer=None) -> None:
     """dW, db of one conv from its forward input and output gradient (NHWC); handed to the gradient reducer at once (DDP runs)."""
     side = _side_stream(dy.device)
     if side is None:
-        new = {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
-        if conv.bias is not None:
-            new[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+        new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid)
         if reducer is not None:
             reducer.push(new)
     else:
         main = torch.cuda.current_stream(dy.device)
         side.wait_stream(main)                              # dy (and x_in) are complete on the main stream up to here
         with torch.cuda.stream(side):
-            new = {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
-            if conv.bias is not None:
-                new[conv.bias] = ops.colsum(dy, conv.cout if cvalid is None else cvalid)
+            new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid)
             if reducer is not None:
                 reducer.push(new)                           # bucket copies + all-reduce start behind the wgrad kernels, on THEIR stream
         for t in (x_in, dy):

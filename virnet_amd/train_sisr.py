@@ -53,8 +53,10 @@ class _Conv3x3(torch.autograd.Function):
                 dx = ops.conv_mfma(ops.zero_stuff2(dy), conv.packed_dgrad(), want_raw=True)[0]
             else:
                 dx = ops.conv_mfma(dy, conv.packed_dgrad(), want_raw=True)[0]
-        dw = ops.conv_wgrad(x, dy, tuple(conv.weight.shape), stride=stride)
-        db = ops.colsum(dy) if conv.bias is not None else None
+        if conv.bias is not None:
+            dw, db = ops.conv_wgrad(x, dy, tuple(conv.weight.shape), stride=stride, bias_channels=dy.shape[-1])
+        else:
+            dw, db = ops.conv_wgrad(x, dy, tuple(conv.weight.shape), stride=stride), None
         return dx, dw, db, None, None
 
 
@@ -99,8 +101,10 @@ class _ConvExit(torch.autograd.Function):
         n, hp, wp, _ = x.shape
         g16 = ops.pack_input(dy.contiguous(), hp, wp, zero_pad=True)           # gradient records, zero beyond the crop
         dx = ops.conv_mfma(g16, conv.packed_dgrad(), want_raw=True)[0] if ctx.needs_input_grad[0] else None
-        dw = ops.conv_wgrad(x, g16, tuple(conv.weight.shape))
-        db = ops.colsum(g16, conv.cout) if conv.bias is not None else None
+        if conv.bias is not None:
+            dw, db = ops.conv_wgrad(x, g16, tuple(conv.weight.shape), bias_channels=conv.cout)
+        else:
+            dw, db = ops.conv_wgrad(x, g16, tuple(conv.weight.shape)), None
         return dx, dw, db, None, None
 
 
