@@ -3,18 +3,20 @@
 //
 //   dW[co][ci][ky][kx] = sum over pixels p of dY[p][co] * A[p + (ky-1, kx-1)][ci]          (A = the forward conv's staged input)
 // contracts over PIXELS, so an MFMA k-step is 16 consecutive pixels of a row and both operands must be CHANNEL-major (8 consecutive
-// pixels of one channel per lane), the transpose of the NHWC tensors the rest of the path uses.  Two kernels:
+// pixels of one channel per lane), the transpose of the NHWC tensors the rest of the path uses.  Three kernels:
 //   1. chsplit_kernel: NHWC fp32 -> channel-major fp16 planes T[n][h+2][c/32][hi|lo][seg][32 ch][8 px] (pixel x at index x+8, one
 //      zero row above and below, zero pads left and right), applying the forward conv's staging transform (lrelu(x*mul+add)) and the
 //      hi/lo split of conv_f16.hip on the way (bf16 variant: one bf16 plane).  Bandwidth-bound; the transpose goes through LDS.
-//   2. conv_wgrad_f16_kernel: workgroup = NWV waves = NWV output-channel blocks x ONE input-channel block, each wave keeping all nine
-//      taps of its (co, ci) pair in registers (144 accumulator VGPRs).  A tile = one image row x 64 pixels: the dY segments and the
-//      three A rows (with their 8-pixel aprons) are contiguous runs of T and come in by LDS-DMA with NO staging arithmetic;
-//      LDS image [seg][32 ch][16 B] -> conflict-free ds_read_b128 fragments.  The kx = 0 / 2 taps are the aligned window shifted by
-//      one pixel = 2 bytes: v_alignbyte over the window's 4 + 2 dwords.  Three products per k-step as in conv_f16.hip (bf16: one).
-//      Tiles are split across workgroups (split-K); partial sums are added to dW with fp32 atomics (dW zeroed by the caller).
+//   2. conv_wgrad_f16_kernel: one workgroup per CU = NWV (<= 3) output-channel blocks x 4 k-step waves, ONE input-channel block, each
+//      wave keeping all nine taps of its (co, ci) pair in registers (144 accumulator VGPRs).  A step = one image row x 64 pixels; the
+//      dY segments and the one new A row of a step are contiguous runs of T and come in by LDS-DMA with NO staging arithmetic, two
+//      steps ahead; LDS image [seg][32 ch][16 B] -> conflict-free ds_read_b128 fragments.  The kx = 0 / 2 taps are the aligned window
+//      shifted by one pixel = 2 bytes: v_alignbyte over the window's 4 + 2 dwords.  Three products per k-step as in conv_f16.hip
+//      (bf16: one).  The pixel range is split across workgroups; their partial sums go to a scratch tensor with plain stores.
+//   3. wgrad_reduce_kernel adds the partial sums in a fixed order and writes dW in OIHW: no atomics, bitwise reproducible.
+// The bias gradient (sum of dY over pixels) is a by-product of pass 1 over dY (per-block channel sums + colpart_reduce_kernel).
 // Accuracy: as conv_f16.hip for operands above fp16's subnormal range; gradients far below 6e-5 in magnitude lose relative precision
-// (absolute error <= 3e-8 per element) -- DESIGN.md 7.
+// (absolute error <= 3e-8 per element) -- DESIGN.md 6.
 #include "conv_f16_common.h"
 #include <cstdlib>
 
@@ -305,27 +307,15 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
         bool anyf = false;
 #pragma unroll
         for (int j = 0; j < DIST - 1; ++j) anyf |= pf[j];
-#ifdef WG_NOWAIT
-        if (t + 1 < t1) wait_vm_barrier<63>(); else wait_vm_barrier<0>();
-#else
         if (ahead == DIST - 1 && !anyf) wait_vm_barrier<(DIST - 1) * PN>();
         else wait_vm_barrier<0>();
-#endif
       }
       WT_ADD(tw, tmark);
       // every wave is past step t-1: its slots are free for the request DIST-1 steps ahead
 #pragma unroll
       for (int j = 0; j + 1 < DIST - 1; ++j) pf[j] = pf[j + 1];
-#ifdef WG_NODMA
-      if (iu < t1 && a.n < 0) { pf[DIST - 2] = issue(false); } else { pf[DIST - 2] = false; --ahead; }
-#else
       if (iu < t1) { pf[DIST - 2] = issue(false); } else { pf[DIST - 2] = false; --ahead; }
-#endif
-#ifdef WG_NOMFMA
-      if (active && a.n < 0) {
-#else
       if (active) {
-#endif
         // one lane-dependent LDS offset for both operands; everything else is a scalar (slot / stage / plane) plus an immediate
         // (lane16 = lhi * 512 + l31 * 16 is also this lane's fragment offset inside a row / dY image; the k-step adds kg * 1024.)
         // The scalar parts are re-derived per read (opaque to CSE): hoisted per-row addresses would cost seven live registers.
@@ -337,12 +327,7 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
           const int plane = ph == 2 ? 1 : 0;
           unsigned so_y = ybs + ((!BF && ph == 0) ? YPL : 0);
           asm volatile("" : "+s"(so_y));
-#ifdef WG_NOLDS
-          h8 af = __builtin_bit_cast(h8, u32x4{lane16, lane16 + 1, lane16 + 2, lane16 + 3});
-          if (a.n < 0) af = *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
-#else
           const h8 af = *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
-#endif
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
             // window of this k-step: segment 1 + 2kg + lhi of the row; xb points ONE segment earlier so that the three reads
@@ -350,19 +335,9 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
             unsigned so_x = ((ccnt + r) % RING) * XROW + plane * XPL + kg * 1024;
             asm volatile("" : "+s"(so_x));
             const char* const xb = smem + (lane16 + so_x);
-#ifdef WG_NOLDS
-            u32x4 d = u32x4{so_x, so_x + 1, lane16, lane16 + 7};
-            unsigned dm = so_x + 5, dp = so_x + 9;
-            if (a.n < 0) {
-              d = *reinterpret_cast<const u32x4*>(xb + 512);
-              dm = *reinterpret_cast<const unsigned*>(xb + 12);
-              dp = *reinterpret_cast<const unsigned*>(xb + 1024);
-            }
-#else
             const u32x4 d = *reinterpret_cast<const u32x4*>(xb + 512);
             const unsigned dm = *reinterpret_cast<const unsigned*>(xb + 12);
             const unsigned dp = *reinterpret_cast<const unsigned*>(xb + 1024);
-#endif
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
               u32x4 f = d;
