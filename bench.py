@@ -190,10 +190,14 @@ def main():
 
         from virnet_amd.loss import elbo_denoising_simple
 
+        # N > 1: data-parallel training as train_denoising_syn.py:71 (DDP) -- gradients averaged over the ranks every step, the
+        # bucketed RCCL all-reduces started from inside the backward (virnet_amd/dist.py)
+        model = vdist.DistributedTrainer(net) if world > 1 else net
+
         def fwd(t):
             for p in net.parameters():
                 p.grad = None
-            mu_, sig_ = net(t)
+            mu_, sig_ = model(t)
             loss = elbo_denoising_simple(mu_, sig_, t, gt, eps2, alpha0, beta0)[0]
             loss.backward()
             if opt is not None:
@@ -281,7 +285,9 @@ def main():
                                    + f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
                        "arithmetic": "fp32 tensors and accumulation; C->C 3x3 convs: " + FORMS[ops.conv_form()][2],
-                       "parallelism": f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), no per-image collective"},
+                       "parallelism": (f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), "
+                                       + ("gradient all-reduce per step (fp32, 8 MB buckets, started inside the backward)" if (training and world > 1)
+                                          else "no per-image collective"))},
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roof,

@@ -122,3 +122,23 @@ def test_bench_self_spawns_two_ranks():
     assert "42157328 B" in d["config"]["parallelism"]              # the one flat weight broadcast: 10 539 332 fp32 parameters
     assert d["value"] > 0 and d["value"] == pytest.approx(64 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-3)
     assert 0.0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_bench_train_two_ranks_averages_gradients():
+    """`bench.py --task train --gpus 2`: the training step of the 2-rank job is data-parallel (DistributedTrainer: gradients all-reduced
+    inside the backward), and says so in its JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIRNET_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--task", "train", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "4", "--size", "64", "--no-cpu-baseline", "--no-roofline"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "gradient all-reduce per step" in d["config"]["parallelism"]
+    assert d["config"]["global_batch"] == 8 and d["value"] > 0
