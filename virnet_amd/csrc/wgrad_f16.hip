@@ -409,22 +409,31 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
     for (int r = 0; r < 16; ++r) part[((size_t)t * cop + (r & 3) + 8 * (r >> 2)) * cip] = acc[t][r];
 }
 
-// dw[co][ci][t] = sum over runs of part[run][t][co][ci]   (thread = one (t, co, ci); consecutive threads = consecutive ci)
+// dw[co][ci][t] = sum over runs of part[run][t][co][ci]   (thread = one (t, co, ci); consecutive threads = consecutive ci).
+// Latency-bound (one dependent chain of nrun loads per thread): sixteen loads in flight per thread; the partial sums are added in
+// run order within each of the sixteen strided chains and the chains in a fixed tree -> bitwise reproducible.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int per = 9 * cop * cip;
   if (i >= per) return;
   const int ci = i % cip, co = (i / cip) % cop, t = i / (cip * cop);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (co >= cout || ci >= cin) return;
+  float s[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s[k] = 0.f;
   int r = 0;
-  for (; r + 4 <= nrun; r += 4) {
-    s0 += part[(size_t)r * per + i];
-    s1 += part[(size_t)(r + 1) * per + i];
-    s2 += part[(size_t)(r + 2) * per + i];
-    s3 += part[(size_t)(r + 3) * per + i];
+  for (; r + 16 <= nrun; r += 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s[k] += part[(size_t)(r + k) * per + i];
   }
-  for (; r < nrun; ++r) s0 += part[(size_t)r * per + i];
-  if (co < cout && ci < cin) dw[((size_t)co * cin + ci) * 9 + t] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (r + k < nrun) s[k] += part[(size_t)(r + k) * per + i];
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+    for (int k = 0; k < w; ++k) s[k] += s[k + w];
+  dw[((size_t)co * cin + ci) * 9 + t] = s[0];
 }
 
 constexpr int kKG = 4;                                    // k-steps (waves) per channel block: 64-pixel steps

@@ -530,12 +530,13 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
         cin, cout, ks = weight_shape[0], weight_shape[1], 1
     else:
         cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
-    dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     form = conv_form()
     if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16")
             and os.environ.get("VIRNET_WGRAD_FORM", "f16") != "f32"):
+        dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
         return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
                                bias_channels=bias_channels)
+    dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     rows = 4 * cout if transposed else cout
     ctr = torch.zeros(((rows + 31) // 32) * ((cin + 31) // 32), dtype=torch.int32, device=x.device)
     d = nat.WgradDesc(x=nat.ptr(x), dy=nat.ptr(dy), in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add), dw=nat.ptr(dw),
