@@ -98,11 +98,13 @@ _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 
 
 def _side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
-    """Second HIP stream for the weight-gradient kernels: they only depend on tensors the input-gradient chain has already
-    produced, so they run beside the next layers' dgrad kernels and the launch tails of both fill (measured +5.7 % on the
-    training step).  VIRNET_WGRAD_STREAM=0 keeps everything on one stream."""
+    """Optional second HIP stream for the weight-gradient kernels (VIRNET_WGRAD_STREAM=1): they only depend on tensors the
+    input-gradient chain has already produced, so they can run beside the next layers' dgrad kernels.  OFF by default since the weight
+    gradients moved to the f16 pipe: every kernel of the step now fills the chip on its own, one stream measures 1 006-1 010 img/s run
+    after run, two streams 1 016-1 030 at best and 635-870 when the host runs ahead of the device (tensors handed across streams
+    pin their blocks in the caching allocator until the device catches up, and the step starts paying for fresh allocations)."""
     import os
-    if os.environ.get("VIRNET_WGRAD_STREAM", "1") == "0":
+    if os.environ.get("VIRNET_WGRAD_STREAM", "0") != "1":
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _SIDE:
