@@ -119,9 +119,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256, help="image height=width")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 @256, 64 @128)")
-    ap.add_argument("--task", default="denoise", choices=["denoise", "sisr", "train"],
+    ap.add_argument("--task", default="denoise", choices=["denoise", "sisr", "train", "train_sisr"],
                     help="sisr = BASELINE configs[3]: VIRAttResUNetSR x4 on LR 64x64 (-> 256x256), 16 images per GPU; "
-                         "train = configs[4]: denoise-syn forward + ELBO + backward (+Adam with --optimizer) on 128x128, 32 per GPU, fp32")
+                         "train = configs[4]: denoise-syn forward + ELBO + backward (+Adam with --optimizer) on 128x128, 32 per GPU, fp32; "
+                         "train_sisr = the SISR step (train_SISR.py:207-224) on configs[3]'s shape: forward x4 + elbo_sisr + backward")
     ap.add_argument("--optimizer", action="store_true", help="train task: include grad clipping + Adam step in the timed step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="train task: bf16 = BASELINE configs[4]'s variant -- the C->C 3x3 convs of forward and backward (input gradients) run "
@@ -129,15 +130,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
-    sisr = args.task == "sisr"
-    training = args.task == "train"
+    sisr = args.task in ("sisr", "train_sisr")
+    training = args.task in ("train", "train_sisr")
+    train_sisr = args.task == "train_sisr"
     if args.dtype == "bf16":
         if not training:
             raise SystemExit("--dtype bf16 is the training variant (inference must be fp32-class: BASELINE.md, 7.5e-3 error at bf16)")
         os.environ["VIRNET_CONV_FORM"] = "bf16"
     if sisr and args.size == 256:
         args.size = 64                      # LR size; the output is 4x
-    if training and args.size == 256:
+    if training and not sisr and args.size == 256:
         args.size = 128                     # configs/denoising_syn.json:6 patch_size
     batch = args.batch if args.batch is not None else (16 if sisr else 32 if (training or args.size >= 256) else 64)
 
@@ -176,7 +178,34 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    if training:
+    if train_sisr:
+        # one step of train_SISR.py:207-224 on resident synthetic data: forward (x4), elbo_sisr (host-side PyTorch, ELBO_simple.py:82-138),
+        # backward through the per-conv HIP kernels; optionally the three clip_grad_norm_ + Adam
+        from virnet_amd.loss import elbo_sisr
+        net.train()
+        nloc = b - a
+        im_hr = synth_images(nloc, 3, args.size * 4, args.size * 4, seed=7 + rank).to(dev)
+        kinfo_gt = torch.tensor([[1.2, 0.8, 0.1]], device=dev).repeat(nloc, 1)
+        nlevel = torch.full((nloc, 1, 1, 1), 2e-3, device=dev)
+        alpha0 = 0.5 * torch.tensor([9.0 ** 2], device=dev)
+        kappa0 = torch.tensor([50.0], device=dev)
+        opt = torch.optim.Adam(net.parameters(), lr=2e-4) if args.optimizer else None
+        groups = {key: [p for nm, p in net.named_parameters() if key in nm.lower()] for key in ("rnet", "snet", "knet")}
+
+        def fwd(t):
+            for p in net.parameters():
+                p.grad = None
+            mu_, kinfo_, sig_ = net(t, 4)
+            loss = elbo_sisr(mu=mu_, sigma_est=sig_, kinfo_est=kinfo_, im_hr=im_hr, im_lr=t, sigma_prior=nlevel, alpha0=alpha0, kinfo_gt=kinfo_gt,
+                             kappa0=kappa0, r2=1e-4, eps2=1e-5, sf=4, k_size=21, penalty_K=[0.02, 2], shift=False, downsampler="Bicubic")[0]
+            loss.backward()
+            if opt is not None:
+                torch.nn.utils.clip_grad_norm_(groups["rnet"], 5e2)
+                torch.nn.utils.clip_grad_norm_(groups["snet"], 1e2)
+                torch.nn.utils.clip_grad_norm_(groups["knet"], 5e2)
+                opt.step()
+            return (mu_.detach(),)
+    elif training:
         # one step of train_denoising_syn.py:171-184 on resident synthetic data: forward, ELBO (host-side PyTorch,
         # loss/ELBO_simple.py:23-53), backward through the HIP kernels, optionally clip + Adam
         net.train()
@@ -274,7 +303,8 @@ def main():
         if training:
             gflop_img *= 3.0                  # forward + input-gradient + weight-gradient convs (~3x forward)
         out = {
-            "metric": (f"images/sec (denoise-syn training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, {args.size}x{args.size}x3)" if training else
+            "metric": (f"images/sec (SISR x4 training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if train_sisr else
+                       f"images/sec (denoise-syn training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, {args.size}x{args.size}x3)" if training else
                        f"images/sec (SISR x4 fwd, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if sisr else
                        "images/sec (256x256x3 denoise fwd)" if args.size == 256 else f"images/sec ({args.size}x{args.size}x3 denoise fwd)"),
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -286,7 +316,7 @@ def main():
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
                        "arithmetic": "fp32 tensors and accumulation; C->C 3x3 convs: " + FORMS[ops.conv_form()][2],
                        "parallelism": (f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), "
-                                       + ("gradient all-reduce per step (fp32, 8 MB buckets, started inside the backward)" if (training and world > 1)
+                                       + ("gradient all-reduce per step (fp32, 8 MB buckets, started inside the backward)" if (training and not train_sisr and world > 1)
                                           else "no per-image collective"))},
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
