@@ -229,6 +229,11 @@ int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float
                    int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream);
 int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
                           int bf16, void* stream);
+/* Backward of the SFT pre-activation a = lrelu(x*mul + add, slope) with per-image [n][c] vectors (AttResUNet.py:54-58), given da = dL/da:
+ * du = da * lrelu'(x*mul+add);  dx = du*mul (+ res, the skip gradient, may be NULL);  dmul[n][c] += sum_p du*x;  dadd[n][c] += sum_p du
+ * (zero dmul / dadd first).  NHWC tensors of n images x hw pixels x c channels (c % 4 == 0). */
+int virnet_sft_backward(const float* da, const float* x, const float* mul, const float* add, const float* res, float slope, float* dx,
+                        float* dmul, float* dadd, int n, long hw, int c, void* stream);
 /* db[c] += sum over pixels of dy[p][c], c < cvalid (NHWC rows of `c` stored channels, c % 4 == 0); zero db first */
 int virnet_colsum(const float* dy, float* db, long npix, int c, int cvalid, void* stream);
 /* z[n][2h][2w][c] = dy at even positions, 0 elsewhere: the stride-2 conv's dgrad is a stride-1 conv of z (AttResUNet.py:67) */

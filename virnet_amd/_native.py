@@ -102,6 +102,8 @@ SYMBOLS = [
     ("virnet_pack_thin_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv3x3_thin", C.c_int, [C.POINTER(ThinDesc), C.c_void_p]),
     ("virnet_conv_wgrad", C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    ("virnet_sft_backward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_long, C.c_int, C.c_void_p]),
     ("virnet_chsplit_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     ("virnet_conv_wgrad_f16_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("virnet_chsplit_colsum_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

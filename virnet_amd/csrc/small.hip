@@ -146,6 +146,54 @@ __global__ __launch_bounds__(256) void scale_add_kernel(const float4* __restrict
   }
 }
 
+// Backward of the SFT pre-activation a = lrelu(u), u = x*mul + add with per-image vectors (AttResUNet.py:54-58; training step of the
+// SISR model): from dA = dL/da,  du = dA * lrelu'(u);  dx = du * mul (+ res: the skip gradient);  dmul[n][c] += sum_p du * x;
+// dadd[n][c] += sum_p du.  One pass over the two tensors; a block walks a run of pixels of ONE image with a fixed channel quad per
+// thread, so the per-image sums stay in registers until one LDS reduction + 2*C atomics per block.  grid (chunks, n).
+__global__ __launch_bounds__(256) void sft_backward_kernel(const float4* __restrict__ da, const float4* __restrict__ x, const float* __restrict__ mul,
+                                                           const float* __restrict__ add, const float4* __restrict__ res, float slope,
+                                                           float4* __restrict__ dx, float* __restrict__ dmul, float* __restrict__ dadd, long hw, int c4,
+                                                           int chunk) {
+  __shared__ float4 rm[256], ra[256];
+  const int img = blockIdx.y;
+  const int pl_n = 256 / c4;                               // pixel lanes per block
+  const int q = threadIdx.x % c4, pl = threadIdx.x / c4;
+  float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sa = sm;
+  if (pl < pl_n) {
+    const float4 m4 = reinterpret_cast<const float4*>(mul + (size_t)img * c4 * 4)[q];
+    const float4 a4 = reinterpret_cast<const float4*>(add + (size_t)img * c4 * 4)[q];
+    const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < hw ? p0 + chunk : hw;
+    for (long p = p0 + pl; p < p1; p += pl_n) {
+      const size_t i = ((size_t)img * hw + p) * c4 + q;
+      const float4 g = da[i], v = x[i];
+      float4 du;
+      du.x = fmaf(v.x, m4.x, a4.x) > 0.f ? g.x : g.x * slope;
+      du.y = fmaf(v.y, m4.y, a4.y) > 0.f ? g.y : g.y * slope;
+      du.z = fmaf(v.z, m4.z, a4.z) > 0.f ? g.z : g.z * slope;
+      du.w = fmaf(v.w, m4.w, a4.w) > 0.f ? g.w : g.w * slope;
+      float4 o = make_float4(du.x * m4.x, du.y * m4.y, du.z * m4.z, du.w * m4.w);
+      if (res) { const float4 r = res[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+      dx[i] = o;
+      sm.x = fmaf(du.x, v.x, sm.x); sm.y = fmaf(du.y, v.y, sm.y); sm.z = fmaf(du.z, v.z, sm.z); sm.w = fmaf(du.w, v.w, sm.w);
+      sa.x += du.x; sa.y += du.y; sa.z += du.z; sa.w += du.w;
+    }
+  }
+  rm[threadIdx.x] = sm; ra[threadIdx.x] = sa;
+  __syncthreads();
+  if (threadIdx.x < c4) {
+    float4 tm = rm[threadIdx.x], ta = ra[threadIdx.x];
+    for (int k = 1; k < pl_n; ++k) {
+      const float4 um = rm[threadIdx.x + k * c4], ua = ra[threadIdx.x + k * c4];
+      tm.x += um.x; tm.y += um.y; tm.z += um.z; tm.w += um.w;
+      ta.x += ua.x; ta.y += ua.y; ta.z += ua.z; ta.w += ua.w;
+    }
+    float* const om = dmul + ((size_t)img * c4 + threadIdx.x) * 4;
+    float* const oa = dadd + ((size_t)img * c4 + threadIdx.x) * 4;
+    atomicAdd(om + 0, tm.x); atomicAdd(om + 1, tm.y); atomicAdd(om + 2, tm.z); atomicAdd(om + 3, tm.w);
+    atomicAdd(oa + 0, ta.x); atomicAdd(oa + 1, ta.y); atomicAdd(oa + 2, ta.z); atomicAdd(oa + 3, ta.w);
+  }
+}
+
 // AttLayer on a per-image vector: block per image
 __global__ __launch_bounds__(256) void sft_vec_kernel(const float* __restrict__ vec, const virnet_sft_weights wt,
                                                       float* __restrict__ mul, float* __restrict__ add) {
@@ -310,6 +358,18 @@ extern "C" int virnet_scale_add(const float* hcv, const float* gate, const float
                      reinterpret_cast<const float4*>(hcv), gate, reinterpret_cast<const float4*>(skip),
                      reinterpret_cast<float4*>(out), hw, c / 4, total4);
   return virnet::check_launch("scale_add launch");
+}
+
+extern "C" int virnet_sft_backward(const float* da, const float* x, const float* mul, const float* add, const float* res, float slope, float* dx,
+                                   float* dmul, float* dadd, int n, long hw, int c, void* stream) {
+  VIRNET_REQUIRE(da && x && mul && add && dx && dmul && dadd, "virnet_sft_backward: NULL pointer");
+  VIRNET_REQUIRE(n > 0 && hw > 0 && c > 0 && c % 4 == 0 && c <= 1024, "virnet_sft_backward: bad shape n=%d hw=%ld c=%d (c %% 4 == 0, c <= 1024)", n, hw, c);
+  VIRNET_REQUIRE(slope >= 0.f && slope <= 1.f, "virnet_sft_backward: slope=%g outside [0,1]", slope);
+  const int chunk = 1024;
+  hipLaunchKernelGGL(sft_backward_kernel, dim3((unsigned)((hw + chunk - 1) / chunk), n), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(da), reinterpret_cast<const float4*>(x), mul, add, reinterpret_cast<const float4*>(res), slope,
+                     reinterpret_cast<float4*>(dx), dmul, dadd, hw, c / 4, chunk);
+  return virnet::check_launch("sft_backward launch");
 }
 
 extern "C" int virnet_sft_vec(const float* vec, const virnet_sft_weights* wt, float* mul, float* add, int n, void* stream) {

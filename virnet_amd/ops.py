@@ -612,6 +612,26 @@ def colsum(dy: Tensor, cvalid: Optional[int] = None) -> Tensor:
     return db
 
 
+def sft_backward(da: Tensor, x: Tensor, mul: Tensor, add: Tensor, *, slope: float = 0.2, res: Optional[Tensor] = None):
+    """Backward of ``a = leaky_relu(x*mul + add, slope)`` with per-image [N, C] vectors on NHWC tensors:
+    ``(dx (+res), dmul, dadd)`` from ``da`` in one pass (csrc/small.hip::sft_backward_kernel)."""
+    for t, nm in ((da, "da"), (x, "x"), (mul, "mul"), (add, "add")):
+        _dev_check(t, nm)
+    n, h, w, c = x.shape
+    if tuple(da.shape) != (n, h, w, c) or tuple(mul.shape) != (n, c) or tuple(add.shape) != (n, c):
+        raise ValueError(f"sft_backward: da {tuple(da.shape)} / mul {tuple(mul.shape)} / add {tuple(add.shape)} do not match x {tuple(x.shape)}")
+    if res is not None:
+        _dev_check(res, "res")
+        if tuple(res.shape) != (n, h, w, c):
+            raise ValueError(f"sft_backward: res {tuple(res.shape)} != {(n, h, w, c)}")
+    dx = torch.empty_like(x)
+    dmul = torch.zeros((n, c), dtype=torch.float32, device=x.device)
+    dadd = torch.zeros((n, c), dtype=torch.float32, device=x.device)
+    nat.check(nat.load().virnet_sft_backward(nat.ptr(da), nat.ptr(x), nat.ptr(mul), nat.ptr(add), nat.ptr(res), slope, nat.ptr(dx), nat.ptr(dmul),
+                                             nat.ptr(dadd), n, h * w, c, nat.stream_handle()), "sft_backward")
+    return dx, dmul, dadd
+
+
 def zero_stuff2(dy: Tensor) -> Tensor:
     _dev_check(dy, "dy")
     n, h, w, c = dy.shape

@@ -3,10 +3,11 @@
 ``VIRAttResUNetSR.forward`` routes here when gradients are enabled.  Every convolution -- forward, input gradient and weight gradient
 -- runs on the C-ABI kernels through small ``torch.autograd.Function`` wrappers (the same kernels the denoiser's training step uses:
 ``virnet_conv_mfma`` / ``virnet_conv_f16`` with the dgrad packings, ``virnet_conv_wgrad``, ``virnet_colsum``, plus
-``virnet_conv_head_s4`` / ``virnet_conv_head_s4_wgrad`` for KNet's 9x9 stride-4 entry).  What sits BETWEEN the convolutions in this
-model -- the SFT modulation ``lrelu(x*mul+add)`` with per-image vectors, the AttLayer / CALayer MLPs on [N, C] vectors, global average
-pools, ``exp(clamp)`` / ``tanh`` -- is expressed as PyTorch device ops on the NHWC tensors and differentiated by autograd: host-side
-tensor plumbing in BASELINE.json's sense, unfused for now (the inference path fuses all of it into the conv prologues / epilogues).
+``virnet_conv_head_s4`` / ``virnet_conv_head_s4_wgrad`` for KNet's 9x9 stride-4 entry).  A residual block is one node: the SFT
+modulation ``lrelu(x*mul+add)`` with per-image vectors and the plain LeakyReLUs ride in the convs' input staging, their backward in the
+dgrad convs' mask epilogue or one ``virnet_sft_backward`` pass.  What is left BETWEEN the nodes -- the AttLayer / CALayer MLPs on [N, C]
+vectors, global average pools, the CALayer gate, ``exp(clamp)`` / ``tanh`` -- is PyTorch device ops differentiated by autograd:
+host-side tensor plumbing in BASELINE.json's sense.
 So the numbers match the inference forward to fp32 noise, the step is complete (every one of the 225 parameters receives its gradient),
 and torch's DistributedDataParallel hooks fire layer by layer as the backward proceeds.
 
@@ -138,8 +139,85 @@ class _PackRecords(torch.autograd.Function):
         return None, dvec, None, None, None
 
 
+def _wgrad(conv, x, dy, **kw):
+    """(dW, db) of a 3x3 conv with bias; db rides on the weight gradient's pass over dy."""
+    if conv.bias is None:
+        return ops.conv_wgrad(x, dy, tuple(conv.weight.shape), **kw), None
+    return ops.conv_wgrad(x, dy, tuple(conv.weight.shape), bias_channels=dy.shape[-1], **kw)
+
+
+class _ResBlockFn(torch.autograd.Function):
+    """AttResBlock (AttResUNet.py:48-60) as ONE autograd node, the way the inference path and the denoiser's training step run it:
+        f1  = conv1(lrelu(x*mul1 + add1))        out = x + conv2(lrelu(f1*mul2 + add2))
+    The SFT modulation and the LeakyReLU are applied while the conv stages its input (``in_mul`` / ``in_add`` / ``in_slope``), the skip
+    is the conv epilogue's ``res``.  Backward: weight gradients with the same staging transform; without SFT the LeakyReLU masks are
+    the dgrad convs' ``mask`` epilogue; with SFT one ``virnet_sft_backward`` pass per conv turns dL/d(activated input) into dL/dx and
+    the per-image dmul / dadd that autograd carries on into the AttLayer MLPs."""
+
+    @staticmethod
+    def forward(ctx, x, mul1, add1, mul2, add2, w1, b1, w2, b2, blk):
+        x = x.contiguous()
+        ctx.blk, ctx.sft = blk, mul1 is not None
+        if ctx.sft:
+            mul1, add1, mul2, add2 = (t.contiguous() for t in (mul1, add1, mul2, add2))
+            f1, _ = ops.conv_mfma(x, blk.conv1.packed(), in_slope=0.2, in_mul=mul1, in_add=add1, want_raw=True)
+            out, _ = ops.conv_mfma(f1, blk.conv2.packed(), in_slope=0.2, in_mul=mul2, in_add=add2, res=x, want_raw=True)
+            ctx.save_for_backward(x, f1, mul1, add1, mul2, add2)
+        else:
+            _, f1a = ops.conv_mfma(x, blk.conv1.packed(), in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
+            out, _ = ops.conv_mfma(f1a, blk.conv2.packed(), res=x, want_raw=True)
+            ctx.save_for_backward(x, f1a)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        blk = ctx.blk
+        dout = dout.contiguous()
+        if ctx.sft:
+            x, f1, mul1, add1, mul2, add2 = ctx.saved_tensors
+            dw2, db2 = _wgrad(blk.conv2, f1, dout, in_slope=0.2, in_mul=mul2, in_add=add2)
+            da2, _ = ops.conv_mfma(dout, blk.conv2.packed_dgrad(), want_raw=True)
+            df1, dmul2, dadd2 = ops.sft_backward(da2, f1, mul2, add2, slope=0.2)
+            dw1, db1 = _wgrad(blk.conv1, x, df1, in_slope=0.2, in_mul=mul1, in_add=add1)
+            da1, _ = ops.conv_mfma(df1, blk.conv1.packed_dgrad(), want_raw=True)
+            dx, dmul1, dadd1 = ops.sft_backward(da1, x, mul1, add1, slope=0.2, res=dout)
+            return dx, dmul1, dadd1, dmul2, dadd2, dw1, db1, dw2, db2, None
+        x, f1a = ctx.saved_tensors
+        dw2, db2 = _wgrad(blk.conv2, f1a, dout)
+        d_f1, _ = ops.conv_mfma(dout, blk.conv2.packed_dgrad(), mask=f1a, mask_slope=0.2, want_raw=True)
+        dw1, db1 = _wgrad(blk.conv1, x, d_f1, in_slope=0.2)
+        dx, _ = ops.conv_mfma(d_f1, blk.conv1.packed_dgrad(), mask=x, mask_slope=0.2, res=dout, want_raw=True)
+        return dx, None, None, None, None, dw1, db1, dw2, db2, None
+
+
+class _ActConv(torch.autograd.Function):
+    """y = conv3x3(lrelu(x, slope)) with the activation applied in the conv's input staging (DnCNN's and RB_Layer's conv -> LReLU ->
+    conv chains, DnCNN.py:22-29 / KNet.py:32-34, re-associated so that each node owns the activation of its INPUT)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, slope):
+        x = x.contiguous()
+        y, _ = ops.conv_mfma(x, conv.packed(), in_slope=slope, want_raw=True)
+        ctx.save_for_backward(x)
+        ctx.conv, ctx.slope = conv, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        conv, slope = ctx.conv, ctx.slope
+        dy = dy.contiguous()
+        dx = ops.conv_mfma(dy, conv.packed_dgrad(), mask=x, mask_slope=slope, want_raw=True)[0] if ctx.needs_input_grad[0] else None
+        dw, db = _wgrad(conv, x, dy, in_slope=slope)
+        return dx, dw, db, None, None
+
+
 def _conv(x: Tensor, conv, stride: int = 1) -> Tensor:
     return _Conv3x3.apply(x, conv.weight, conv.bias, conv, stride)
+
+
+def _act_conv(x: Tensor, conv, slope: float) -> Tensor:
+    return _ActConv.apply(x, conv.weight, conv.bias, conv, slope)
 
 
 def _lin(v: Tensor, conv) -> Tensor:
@@ -155,17 +233,13 @@ def _att_layer(vec: Tensor, att) -> Tuple[Tensor, Tensor]:
 
 
 def _res_block(x: Tensor, blk, vec: Optional[Tensor]) -> Tensor:
-    """AttResBlock.forward (AttResUNet.py:48-60) on NHWC tensors."""
+    """AttResBlock.forward (AttResUNet.py:48-60) on NHWC tensors: one fused node (the AttLayer MLPs stay autograd on [N, C] vectors)."""
+    c1, c2 = blk.conv1, blk.conv2
     if vec is not None and blk.extra_chn > 0:
         mul1, add1 = _att_layer(vec, blk.sft1)
-        a1 = F.leaky_relu(x * mul1[:, None, None, :] + add1[:, None, None, :], 0.2)
-        f1 = _conv(a1, blk.conv1)
         mul2, add2 = _att_layer(vec, blk.sft2)
-        a2 = F.leaky_relu(f1 * mul2[:, None, None, :] + add2[:, None, None, :], 0.2)
-    else:
-        f1 = _conv(F.leaky_relu(x, 0.2), blk.conv1)
-        a2 = F.leaky_relu(f1, 0.2)
-    return x + _conv(a2, blk.conv2)
+        return _ResBlockFn.apply(x, mul1, add1, mul2, add2, c1.weight, c1.bias, c2.weight, c2.bias, blk)
+    return _ResBlockFn.apply(x, None, None, None, None, c1.weight, c1.bias, c2.weight, c2.bias, blk)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -174,11 +248,11 @@ def _res_block(x: Tensor, blk, vec: Optional[Tensor]) -> Tensor:
 def _snet(snet, x: Tensor) -> Tensor:
     """DnCNN.forward (DnCNN.py:37-44) -> raw log-variance, [N,C,h,w] or pooled [N,C,1,1]."""
     n, _, h, w = x.shape
-    cur = F.leaky_relu(_conv(ops.pack_input(x, h, w), snet.conv1), 0.25)
+    cur = _conv(ops.pack_input(x, h, w), snet.conv1)                # pre-activations; each following conv applies the LReLU on its input
     for key in sorted(snet.mid_layer.keys(), key=int):
-        cur = F.leaky_relu(_conv(cur, snet.mid_layer[key]), 0.25)
+        cur = _act_conv(cur, snet.mid_layer[key], 0.25)
     last = snet.conv_last
-    v = _ConvExit.apply(cur, last.weight, last.bias, last, (h, w))
+    v = _ConvExit.apply(F.leaky_relu(cur, 0.25), last.weight, last.bias, last, (h, w))
     return v.mean(dim=(2, 3), keepdim=True) if snet.noise_avg else v
 
 
@@ -186,8 +260,7 @@ def _knet(knet, x: Tensor) -> Tensor:
     """KernelNet.forward (KNet.py:52-59) -> [N, 3] = (lam1, lam2, rho)."""
     k = _HeadS4.apply(x, knet.head.weight)
     for rb in knet.body:
-        a = F.leaky_relu(_conv(k, rb.body["0"]), 0.2)                           # KNet.py:32-33
-        hcv = _conv(a, rb.body["2"])                                            # KNet.py:34
+        hcv = _act_conv(_conv(k, rb.body["0"]), rb.body["2"], 0.2)              # KNet.py:32-34 (LReLU in the second conv's staging)
         ca = rb.body["3"].body
         y = F.leaky_relu(_lin(hcv.mean(dim=(1, 2)), ca["0"]), 0.2)              # KNet.py:15-19
         gate = torch.sigmoid(_lin(y, ca["2"]))
