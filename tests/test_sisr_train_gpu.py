@@ -108,3 +108,23 @@ def test_sisr_training_rejects_what_is_not_built():
     net2, _ = build(SMALL)
     with pytest.raises(RuntimeError, match="input image"):
         net2(synth_images(1, 3, 8, 8).cuda().requires_grad_(True), 2)
+
+
+@pytest.mark.parametrize("n,h,w,c,with_res", [(2, 9, 13, 96, True), (3, 7, 5, 160, False), (1, 33, 40, 224, True), (2, 4, 4, 8, False)])
+def test_sft_backward_kernel_vs_autograd(n, h, w, c, with_res):
+    """virnet_sft_backward: gradients of a = lrelu(x*mul + add, 0.2) w.r.t. x, mul, add (AttResUNet.py:54-58) from dL/da, + the skip."""
+    from virnet_amd import ops
+    g = torch.Generator().manual_seed(40 + c)
+    x = (torch.rand(n, h, w, c, generator=g) - 0.5).requires_grad_(True)
+    mul = (0.3 + torch.rand(n, c, generator=g)).requires_grad_(True)
+    add = (torch.rand(n, c, generator=g) - 0.5).requires_grad_(True)
+    da = torch.rand(n, h, w, c, generator=g) - 0.5
+    res = torch.rand(n, h, w, c, generator=g) - 0.5 if with_res else None
+    a = torch.nn.functional.leaky_relu(x * mul[:, None, None, :] + add[:, None, None, :], 0.2)
+    a.backward(da)
+    dx, dmul, dadd = ops.sft_backward(da.cuda(), x.detach().cuda(), mul.detach().cuda(), add.detach().cuda(), slope=0.2,
+                                      res=None if res is None else res.cuda())
+    ref_dx = x.grad + (res if with_res else 0)
+    assert float((dx.cpu() - ref_dx).abs().max()) <= 1e-6
+    assert float((dmul.cpu() - mul.grad).abs().max()) <= 2e-5 * max(1.0, float(mul.grad.abs().max()))
+    assert float((dadd.cpu() - add.grad).abs().max()) <= 2e-5 * max(1.0, float(add.grad.abs().max()))
