@@ -436,16 +436,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[((size_t)co * cin + ci) * 9 + t] = s[0];
 }
 
-constexpr int kKG = 4;                                    // k-steps (waves) per channel block: 64-pixel steps
-struct Plan { int nwv, pairs, split, run, nxs, nsteps; };
+// k-steps (waves) per channel block: 64-pixel steps = twelve-wave workgroups, one per CU; images of at most 32 columns would waste
+// half of every such step, they take 32-pixel steps = six-wave workgroups, two per CU (2/3/3/4 waves on the SIMDs, still the better deal).
+struct Plan { int kg, nwv, pairs, split, run, nxs, nsteps; };
 inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
   Plan p;
+  p.kg = w <= 32 ? 2 : 4;
   p.nwv = ncob >= 3 ? 3 : ncob;
-  p.nxs = (w + 16 * kKG - 1) / (16 * kKG);
+  p.nxs = (w + 16 * p.kg - 1) / (16 * p.kg);
   p.nsteps = n * p.nxs * h;
   const int groups = (ncob + p.nwv - 1) / p.nwv;
   p.pairs = groups * ncib;
-  int split = 256 / p.pairs;                             // one workgroup per CU (its LDS rings take most of the 160 KB)
+  int split = (p.kg == 2 ? 512 : 256) / p.pairs;         // workgroups per CU: the LDS rings take 142 KB (64-pixel steps) / 78 KB (32)
   if (split > p.nsteps / 4) split = p.nsteps / 4;        // runs of at least four steps (each run primes three rows)
   if (split < 1) split = 1;
   p.run = (p.nsteps + split - 1) / split;
@@ -453,9 +455,8 @@ inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
   return p;
 }
 
-template <int NWV, int BF>
-int launch_g(GArgs k, hipStream_t st) {
-  constexpr int KG = kKG;
+template <int NWV, int BF, int KG>
+int launch_g(GArgs k, const Plan& p, hipStream_t st) {
   constexpr int LDS = WgCfg<BF, KG>::lds(NWV) > 3 * 16 * 64 * 4 * NWV ? WgCfg<BF, KG>::lds(NWV) : 3 * 16 * 64 * 4 * NWV;   // K loop / epilogue exchange
   static unsigned long long attr_done = 0;
   auto kern = conv_wgrad_f16_kernel<NWV, BF, KG>;
@@ -463,10 +464,14 @@ int launch_g(GArgs k, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wgrad_f16): %s", hipGetErrorString(e));
   }
-  const Plan p = make_plan(k.n, k.h, k.w, k.ncob, k.ncib);
   k.nxs = p.nxs; k.nsteps = p.nsteps; k.run = p.run; k.nsplit = p.split; k.npairs = p.pairs;
   hipLaunchKernelGGL(kern, dim3(p.pairs * p.split), dim3(64 * KG * NWV), LDS, st, k);
   return virnet::check_launch("conv_wgrad_f16 launch");
+}
+
+template <int BF, int KG>
+int launch_nwv(const GArgs& k, const Plan& p, hipStream_t st) {
+  return p.nwv == 3 ? launch_g<3, BF, KG>(k, p, st) : p.nwv == 2 ? launch_g<2, BF, KG>(k, p, st) : launch_g<1, BF, KG>(k, p, st);
 }
 
 static long long* g_wlog = nullptr;
@@ -525,10 +530,9 @@ extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   GArgs kk = k;
   const Plan p = make_plan(n, h, w, kk.ncob, kk.ncib);
-  const int nwv = p.nwv;
   int rc;
-  if (bf16) rc = nwv == 3 ? launch_g<3, 1>(kk, st) : nwv == 2 ? launch_g<2, 1>(kk, st) : launch_g<1, 1>(kk, st);
-  else rc = nwv == 3 ? launch_g<3, 0>(kk, st) : nwv == 2 ? launch_g<2, 0>(kk, st) : launch_g<1, 0>(kk, st);
+  if (p.kg == 2) rc = bf16 ? launch_nwv<1, 2>(kk, p, st) : launch_nwv<0, 2>(kk, p, st);
+  else rc = bf16 ? launch_nwv<1, 4>(kk, p, st) : launch_nwv<0, 4>(kk, p, st);
   if (rc) return rc;
   const int cop = kk.ncob * 32, cip = kk.ncib * 32;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * cop * cip + 255) / 256), dim3(256), 0, st, scratch, dw, p.split, cop, cip, cout, cin);
