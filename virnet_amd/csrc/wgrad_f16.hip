@@ -29,7 +29,8 @@ struct TGeom {
   int nseg;            // 8-pixel segments per row of T
 };
 
-__host__ __device__ inline int t_nseg(int w) { return 8 * ((w + 63) / 64) + 2; }
+// segments per row of T: the pixels rounded up to whole steps (64 pixels; 32 for images of at most 32 columns) + one pad segment each side
+__host__ __device__ inline int t_nseg(int w) { return w <= 32 ? 6 : 8 * ((w + 63) / 64) + 2; }
 
 // ---- 1. NHWC fp32 -> T -------------------------------------------------------------------------------------------------------------
 // block = (image, padded row, channel block, group of 8 segments); 256 threads
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct Plan { int kg, nwv, pairs, split, run, nxs, nsteps; };
 inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
   Plan p;
-  p.kg = w <= 32 ? 2 : 4;
+  static const int kg_env = getenv("VIRNET_WGRAD_KG") ? atoi(getenv("VIRNET_WGRAD_KG")) : 0;   // tuning override: 2 or 4
+  p.kg = w <= 32 ? 2 : (kg_env == 2 || kg_env == 4 ? kg_env : 4);   // (T rows of narrow images only have room for 32-pixel steps)
   p.nwv = ncob >= 3 ? 3 : ncob;
   p.nxs = (w + 16 * p.kg - 1) / (16 * p.kg);
   p.nsteps = n * p.nxs * h;
