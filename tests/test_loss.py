@@ -63,3 +63,35 @@ def test_elbo_sisr_matches_reference_golden(down):
     assert float(mu.grad.double().sum()) == pytest.approx(c["dmu_sum"], rel=1e-4) and float(mu.grad.abs().max()) == pytest.approx(c["dmu_absmax"], rel=1e-4)
     assert [float(v) for v in sigma.grad.reshape(-1)] == pytest.approx(c["dsigma"], rel=1e-4)
     assert [float(v) for v in kinfo.grad.reshape(-1)] == pytest.approx(c["dkinfo"], rel=2e-3, abs=1e-4)
+
+
+def test_blur_fft_matches_direct_sum_cpu():
+    """The FFT spelling of the degradation blur (used on the device) against the grouped F.conv2d spelling, values and both gradients."""
+    import torch.nn.functional as F
+    from virnet_amd.loss import _xcorr_fft
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w, k = 3, 3, 40, 52, 21
+    x = torch.rand(n, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    ker = torch.rand(n, 1, k, k, generator=g, dtype=torch.float64)
+    ker = (ker / ker.sum((2, 3), keepdim=True)).requires_grad_(True)
+    pad = F.pad(x, (k // 2,) * 4, mode="reflect")
+    ref = F.conv2d(pad.reshape(1, n * c, h + k - 1, w + k - 1), ker.repeat_interleave(c, 0), groups=n * c).view(n, c, h, w)
+    got = _xcorr_fft(pad, ker, h, w)
+    assert float((got - ref).abs().max()) <= 1e-12
+    wgt = torch.rand(n, c, h, w, generator=g, dtype=torch.float64)
+    gx_ref, gk_ref = torch.autograd.grad((ref * wgt).sum(), [x, ker], retain_graph=True)
+    gx, gk = torch.autograd.grad((got * wgt).sum(), [x, ker])
+    assert float((gx - gx_ref).abs().max()) <= 1e-12 and float((gk - gk_ref).abs().max()) <= 1e-10
+
+
+@pytest.mark.gpu
+def test_blur_downsample_device_path_matches_cpu():
+    from virnet_amd.loss import blur_downsample
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 64, 48, generator=g)
+    ker = torch.rand(2, 1, 21, 21, generator=g)
+    ker = ker / ker.sum((2, 3), keepdim=True)
+    for mode in ("direct", "bicubic"):
+        ref = blur_downsample(x, ker, 4, mode)
+        got = blur_downsample(x.cuda(), ker.cuda(), 4, mode).cpu()
+        assert float((got - ref).abs().max()) <= 2e-6

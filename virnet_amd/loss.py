@@ -86,7 +86,10 @@ def blur_downsample(im_hr: Tensor, kernel: Tensor, sf: int, downsampler: str) ->
     n, c, h, w = im_hr.shape
     k = kernel.shape[-1]
     pad = F.pad(im_hr, (k // 2,) * 4, mode="reflect")
-    blur = F.conv2d(pad.reshape(1, n * c, h + 2 * (k // 2), w + 2 * (k // 2)), kernel.repeat_interleave(c, 0), groups=n * c).view(n, c, h, w)
+    if im_hr.is_cuda and k >= 9:
+        blur = _xcorr_fft(pad, kernel, h, w)
+    else:
+        blur = F.conv2d(pad.reshape(1, n * c, h + 2 * (k // 2), w + 2 * (k // 2)), kernel.repeat_interleave(c, 0), groups=n * c).view(n, c, h, w)
     mode = downsampler.lower()
     if mode == "direct":
         return blur[:, :, ::sf, ::sf]
@@ -95,6 +98,18 @@ def blur_downsample(im_hr: Tensor, kernel: Tensor, sf: int, downsampler: str) ->
         aw = _bicubic_matrix(w, sf, blur.device, blur.dtype)
         return ah @ blur @ aw.t()
     raise ValueError("downsampler must be 'direct' or 'bicubic'")
+
+
+def _xcorr_fft(pad: Tensor, kernel: Tensor, h: int, w: int) -> Tensor:
+    """The same per-sample cross-correlation as the grouped ``F.conv2d`` above, through the FFT: on the device the library's depthwise
+    path for 21x21 kernels costs ~9 ms per training step (forward + both gradients) against <1 ms this way.  ``pad`` [N,C,h+k-1,w+k-1],
+    ``kernel`` [N,1,k,k] -> [N,C,h,w]; the transform size is rounded up to a multiple of 32 (no wrap-around reaches the kept region);
+    differentiable in both arguments; agrees with the direct sum to fp32 rounding (tests/test_loss.py)."""
+    hs = -(-pad.shape[-2] // 32) * 32
+    ws = -(-pad.shape[-1] // 32) * 32
+    fx = torch.fft.rfft2(pad, s=(hs, ws))
+    fk = torch.fft.rfft2(kernel, s=(hs, ws))
+    return torch.fft.irfft2(fx * fk.conj(), s=(hs, ws))[..., :h, :w]
 
 
 def reparameter_cov_mat(kinfo_est: Tensor, kappa0: Tensor, rho_var: float) -> Tensor:
