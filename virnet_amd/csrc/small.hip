@@ -48,26 +48,41 @@ __global__ __launch_bounds__(256) void conv_head_s4_kernel(const float* __restri
 }
 
 // Weight gradient of the same layer (SISR training step, train_SISR.py:207-224): dw[co][ci][ky][kx] = sum over images and output
-// pixels of dy[n][oy][ox][co] * x[n][ci][4oy+ky-4][4ox+kx-4].  One block per (ci, ky, kx), one thread per output channel: the input
-// sample is a wave-uniform broadcast, dy is read channel-contiguous.  0.17 % of the SISR FLOPs: latency class, not tuned.
-__global__ __launch_bounds__(64) void conv_head_s4_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                 float* __restrict__ dw, int n, int cin, int h, int wd, int cout,
-                                                                 int oh, int ow) {
+// pixels of dy[n][oy][ox][co] * x[n][ci][4oy+ky-4][4ox+kx-4].  One block per (ci, ky, kx); a thread owns one output channel and a
+// quarter of the (image, output row) pairs (the input sample is a wave-uniform broadcast, dy is read channel-contiguous), the four
+// partial sums meet in LDS.  0.17 % of the SISR FLOPs: latency class.
+__global__ __launch_bounds__(256) void conv_head_s4_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dw, int n, int cin, int h, int wd, int cout,
+                                                                  int oh, int ow) {
+  __shared__ float red[4][64];
   const int kx = blockIdx.x % 9, ky = (blockIdx.x / 9) % 9, ci = blockIdx.x / 81;
-  for (int co = threadIdx.x; co < cout; co += 64) {
-    float acc = 0.f;
-    for (int img = 0; img < n; ++img) {
-      const float* xp = x + ((size_t)img * cin + ci) * h * wd;
-      for (int oy = 0; oy < oh; ++oy) {
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  for (int co0 = 0; co0 < cout; co0 += 64) {
+    const int co = co0 + lane;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (co < cout) {
+      for (int row = part; row < n * oh; row += 4) {         // (image, output row) pairs
+        const int img = row / oh, oy = row - img * oh;
         const int iy = oy * 4 - 4 + ky;
         if ((unsigned)iy >= (unsigned)h) continue;
-        for (int ox = 0; ox < ow; ++ox) {
+        const float* const xp = x + (((size_t)img * cin + ci) * h + iy) * wd;
+        const float* const dp = dy + ((size_t)img * oh + oy) * ow * cout + co;
+        int ox = 0;
+        for (; ox + 1 < ow; ox += 2) {
+          const int ix0 = ox * 4 - 4 + kx, ix1 = ix0 + 4;
+          if ((unsigned)ix0 < (unsigned)wd) acc0 = fmaf(dp[(size_t)ox * cout], xp[ix0], acc0);
+          if ((unsigned)ix1 < (unsigned)wd) acc1 = fmaf(dp[(size_t)(ox + 1) * cout], xp[ix1], acc1);
+        }
+        if (ox < ow) {
           const int ix = ox * 4 - 4 + kx;
-          if ((unsigned)ix < (unsigned)wd) acc = fmaf(dy[(((size_t)img * oh + oy) * ow + ox) * cout + co], xp[(size_t)iy * wd + ix], acc);
+          if ((unsigned)ix < (unsigned)wd) acc0 = fmaf(dp[(size_t)ox * cout], xp[ix], acc0);
         }
       }
     }
-    dw[(((size_t)co * cin + ci) * 9 + ky) * 9 + kx] = acc;
+    red[part][lane] = acc0 + acc1;
+    __syncthreads();
+    if (part == 0 && co < cout) dw[(((size_t)co * cin + ci) * 9 + ky) * 9 + kx] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    __syncthreads();
   }
 }
 
@@ -323,7 +338,7 @@ extern "C" int virnet_conv_head_s4_wgrad(const float* x, const float* dy, float*
   VIRNET_REQUIRE(x && dy && dw, "virnet_conv_head_s4_wgrad: NULL pointer");
   VIRNET_REQUIRE(n > 0 && h > 0 && w_ > 0 && cin > 0 && cout > 0, "virnet_conv_head_s4_wgrad: bad shape");
   const int oh = (h - 1) / 4 + 1, ow = (w_ - 1) / 4 + 1;
-  hipLaunchKernelGGL(conv_head_s4_wgrad_kernel, dim3(cin * 81), dim3(64), 0, static_cast<hipStream_t>(stream), x, dy, dw, n, cin, h,
+  hipLaunchKernelGGL(conv_head_s4_wgrad_kernel, dim3(cin * 81), dim3(256), 0, static_cast<hipStream_t>(stream), x, dy, dw, n, cin, h,
                      w_, cout, oh, ow);
   return virnet::check_launch("conv_head_s4_wgrad launch");
 }
