@@ -127,3 +127,18 @@ def test_wgrad_f16_abi_rejects_bad_arguments():
     assert lib.virnet_conv_wgrad_f16(nat.ptr(buf), nat.ptr(buf), nat.ptr(f), nat.ptr(f), 1, 8, 8, 32, 32, 40, 32, 0, st) != 0   # cin > cx
     assert lib.virnet_conv_wgrad_f16(nat.ptr(buf), nat.ptr(buf), None, nat.ptr(f), 1, 8, 8, 32, 32, 32, 32, 0, st) != 0
     assert b"virnet_conv_wgrad_f16" in nat.last_error() if hasattr(nat, "last_error") else True
+
+
+@pytest.mark.parametrize("n,h,w,c", [(32, 128, 128, 96), (32, 64, 64, 192), (32, 32, 32, 288), (8, 256, 256, 96)])
+def test_wgrad_f16_full_size_against_the_fp32_kernel(n, h, w, c, monkeypatch):
+    """BASELINE configs[4]'s layer shapes (and a 256^2 one): the f16-pipe gradient against the round-1 fp32 MFMA kernel on the same
+    device tensors -- an independent implementation (different tiling, split and reduction), so index arithmetic at full size is covered."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.rand(n, h, w, c, device="cuda", generator=g) - 0.5
+    dy = (torch.rand(n, h, w, c, device="cuda", generator=g) - 0.5) * 0.1
+    dw, db = ops.conv_wgrad(x, dy, (c, c, 3, 3), in_slope=0.2, bias_channels=c)
+    monkeypatch.setenv("VIRNET_WGRAD_FORM", "f32")
+    dw32, db32 = ops.conv_wgrad(x, dy, (c, c, 3, 3), in_slope=0.2, bias_channels=c)
+    scale = float(dw32.abs().max())
+    assert float((dw - dw32).abs().max()) <= 3e-5 * scale
+    assert float((db - db32).abs().max()) <= 3e-5 * float(db32.abs().max())
