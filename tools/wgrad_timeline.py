@@ -43,14 +43,14 @@ print(f"{args.shape}: {len(t)} workgroups, steps/run {t[:, 5].mean():.1f}; s_mem
 import collections
 pat = collections.Counter()
 for row in t:
-    simds = [((int(row[6]) >> (4 * i)) & 0xf) - 1 for i in range(6) if (int(row[6]) >> (4 * i)) & 0xf]
+    simds = [((int(row[6]) >> (4 * i)) & 0xf) - 1 for i in range(12) if (int(row[6]) >> (4 * i)) & 0xf]
     pat[tuple(simds)] += 1
 print("SIMD of waves 0..5 (most common):", pat.most_common(6))
 cu = collections.defaultdict(list)
 for row in t:
     hw = int(row[7]) & 0xffff
     key = (int(row[7]) >> 16, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf)
-    simds = [((int(row[6]) >> (4 * i)) & 0xf) - 1 for i in range(6) if (int(row[6]) >> (4 * i)) & 0xf]
+    simds = [((int(row[6]) >> (4 * i)) & 0xf) - 1 for i in range(12) if (int(row[6]) >> (4 * i)) & 0xf]
     cu[key].append(simds)
 occ = collections.Counter()
 for k, v in cu.items():

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
 #pragma unroll
       for (int j = 0; j + 1 < DIST - 1; ++j) pf[j] = pf[j + 1];
       if (iu < t1) { pf[DIST - 2] = issue(false); } else { pf[DIST - 2] = false; --ahead; }
+      WT_ADD(ti, tmark);
       if (active) {
         // one lane-dependent LDS offset for both operands; everything else is a scalar (slot / stage / plane) plus an immediate
         // (lane16 = lhi * 512 + l31 * 16 is also this lane's fragment offset inside a row / dY image; the k-step adds kg * 1024.)
