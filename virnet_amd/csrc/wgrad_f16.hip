@@ -8,7 +8,9 @@
 //      zero row above and below, zero pads left and right), applying the forward conv's staging transform (lrelu(x*mul+add)) and the
 //      hi/lo split of conv_f16.hip on the way (bf16 variant: one bf16 plane).  Bandwidth-bound; the transpose goes through LDS.
 //   2. conv_wgrad_f16_kernel: one workgroup per CU = NWV (<= 3) output-channel blocks x 4 k-step waves, ONE input-channel block, each
-//      wave keeping all nine taps of its (co, ci) pair in registers (144 accumulator VGPRs).  A step = one image row x 64 pixels; the
+//      wave pair keeping all nine taps of its (co, ci) pair in registers (6 accumulator tiles = 96 VGPRs per wave: the even wave owns tap
+//      rows {0,1}, the odd wave {2,1}, each does both of its rows on its own k-step and its outer row on the partner's).  A step = one
+//      image row x 64 pixels; the
 //      dY segments and the one new A row of a step are contiguous runs of T and come in by LDS-DMA with NO staging arithmetic, two
 //      steps ahead; LDS image [seg][32 ch][16 B] -> conflict-free ds_read_b128 fragments.  The kx = 0 / 2 taps are the aligned window
 //      shifted by one pixel = 2 bytes: v_alignbyte over the window's 4 + 2 dwords.  Three products per k-step as in conv_f16.hip
@@ -142,7 +144,7 @@ struct GArgs {
 // A step = one image row x 16*KG pixels, one MFMA k-step of 16 pixels per wave.  Steps walk DOWN a column strip, so of the three A
 // rows a step reads only one is new.  Operands arrive by LDS-DMA DIST steps ahead of their use (a DMA round trip is ~3 us, a step
 // ~1.5-2 us): a ring of DIST+5 A-row slots and DIST+1 dY stages; every wave issues the SAME number of 1-KB pieces per step so the wait
-// before a step is a literal `s_waitcnt vmcnt(pieces of the later steps)` and never drains the prefetch.  168 registers per wave.
+// before a step is a literal `s_waitcnt vmcnt(pieces of the later steps)` and never drains the prefetch.
 template <int BF, int KG> struct WgCfg {
   static constexpr int NPL = BF ? 1 : 2;
   static constexpr int DIST = BF ? 4 : 2;
@@ -202,9 +204,17 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
   const bool active = cob < a.ncob;
   const size_t plx = (size_t)a.nseg * 512, rowx = (size_t)a.ncib * 2 * plx, rowy = (size_t)a.ncob * 2 * plx;
 
-  f32x16 acc[9];
+  // SIX accumulator tiles per wave, not nine.  The KG waves of a channel block work in pairs on two neighbouring k-steps: the even
+  // wave owns tap rows {0, 1}, the odd wave rows {2, 1}; on its OWN k-step a wave does both of its rows, on its partner's k-step only
+  // its outer row (0 or 2) -- every (row, k-step) is done once, each wave still issues 9 of the pair's 18 (row, k-step, dx-triple)
+  // units, and 96 accumulator registers instead of 144 leave room to read window i+1 while the MFMAs of window i issue.
+  // Tile L0 (acc[0..2]) = outer row r0 = 0 | 2, tile L1 (acc[3..5]) = row 1.  The partial sums of a tap row meet in the epilogue.
+  const int par = kg & 1;
+  const int km = kg, ko = kg ^ 1;                          // own / partner k-step
+  const int r0 = 2 * par;
+  f32x16 acc[6];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 6; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -321,41 +331,54 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
         // one lane-dependent LDS offset for both operands; everything else is a scalar (slot / stage / plane) plus an immediate
         // (lane16 = lhi * 512 + l31 * 16 is also this lane's fragment offset inside a row / dY image; the k-step adds kg * 1024.)
         // The scalar parts are re-derived per read (opaque to CSE): hoisted per-row addresses would cost seven live registers.
-        const unsigned ybs = RING * XROW + ((t - t0) % STAGES) * YST + cw * YW + kg * 1024;
-        // operand-major phases keep ONE dY fragment and one window live at a time (144 accumulators + ~20 registers: three
-        // waves per SIMD): dy_lo * a_hi, dy_hi * a_hi, dy_hi * a_lo  (bf16: the single product)
-#pragma unroll
-        for (int ph = 0; ph < (BF ? 1 : 3); ++ph) {
-          const int plane = ph == 2 ? 1 : 0;
-          unsigned so_y = ybs + ((!BF && ph == 0) ? YPL : 0);
+        const unsigned ybs = RING * XROW + ((t - t0) % STAGES) * YST + cw * YW;
+        // Nine windows per step = 3 operand phases (dy_lo * a_hi, dy_hi * a_hi, dy_hi * a_lo; bf16: one) x [(own k-step, row r0),
+        // (own k-step, row 1), (partner k-step, row r0)].  A window = segment 1 + 2k + lhi of its row; xb points ONE segment earlier so
+        // that the three reads (last dword of the previous segment, the segment, first dword of the next) use non-negative
+        // immediates.  Window i+1 and the next phase's dY fragments are requested before the MFMAs of window i are issued.
+        struct Win { u32x4 d; unsigned dm, dp; };
+        auto load_win = [&](int ph, int i) -> Win {
+          unsigned so_x = ((ccnt + (i == 1 ? 1 : r0)) % RING) * XROW + (ph == 2 ? XPL : 0) + (i == 2 ? ko : km) * 1024;
+          asm volatile("" : "+s"(so_x));
+          const char* const xb = smem + (lane16 + so_x);
+          return Win{*reinterpret_cast<const u32x4*>(xb + 512), *reinterpret_cast<const unsigned*>(xb + 12), *reinterpret_cast<const unsigned*>(xb + 1024)};
+        };
+        auto load_af = [&](int ph, int k) -> h8 {
+          unsigned so_y = ybs + ((!BF && ph == 0) ? YPL : 0) + k * 1024;
           asm volatile("" : "+s"(so_y));
-          const h8 af = *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
+          return *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
+        };
+        constexpr int NPH = BF ? 1 : 3;
+        h8 af_m = load_af(0, km), af_o = load_af(0, ko);
+        Win cur = load_win(0, 0);
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            // window of this k-step: segment 1 + 2kg + lhi of the row; xb points ONE segment earlier so that the three reads
-            // (last dword of the previous segment, the segment, first dword of the next) use non-negative immediates
-            unsigned so_x = ((ccnt + r) % RING) * XROW + plane * XPL + kg * 1024;
-            asm volatile("" : "+s"(so_x));
-            const char* const xb = smem + (lane16 + so_x);
-            const u32x4 d = *reinterpret_cast<const u32x4*>(xb + 512);
-            const unsigned dm = *reinterpret_cast<const unsigned*>(xb + 12);
-            const unsigned dp = *reinterpret_cast<const unsigned*>(xb + 1024);
+        for (int wi = 0; wi < NPH * 3; ++wi) {
+          const int ph = wi / 3, i = wi % 3;
+          Win nxt = cur;
+          if (wi + 1 < NPH * 3) nxt = load_win((wi + 1) / 3, (wi + 1) % 3);
+          h8 nm = af_m, no = af_o;
+          if (i == 2 && ph + 1 < NPH) { nm = load_af(ph + 1, km); no = load_af(ph + 1, ko); }
+          __builtin_amdgcn_sched_barrier(0);             // the requests go out BEFORE this window's MFMAs (left alone, the compiler
+                                                         // sinks them to one MFMA before their wait)
+          const h8 af = i == 2 ? af_o : af_m;
+          const int tb = i == 1 ? 3 : 0;
+          const u32x4 d = cur.d;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-              u32x4 f = d;
-              if (dx == 0)
-                f = u32x4{__builtin_amdgcn_alignbyte(d.x, dm, 2), __builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2),
-                          __builtin_amdgcn_alignbyte(d.w, d.z, 2)};
-              if (dx == 2)
-                f = u32x4{__builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2), __builtin_amdgcn_alignbyte(d.w, d.z, 2),
-                          __builtin_amdgcn_alignbyte(dp, d.w, 2)};
-              if (BF)
-                acc[r * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af), __builtin_bit_cast(b8, f), acc[r * 3 + dx], 0, 0, 0);
-              else
-                acc[r * 3 + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(h8, f), acc[r * 3 + dx], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);           // keep the next window's reads behind these MFMAs (register budget)
+          for (int dx = 0; dx < 3; ++dx) {
+            u32x4 f = d;
+            if (dx == 0)
+              f = u32x4{__builtin_amdgcn_alignbyte(d.x, cur.dm, 2), __builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2),
+                        __builtin_amdgcn_alignbyte(d.w, d.z, 2)};
+            if (dx == 2)
+              f = u32x4{__builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2), __builtin_amdgcn_alignbyte(d.w, d.z, 2),
+                        __builtin_amdgcn_alignbyte(cur.dp, d.w, 2)};
+            if (BF)
+              acc[tb + dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, af), __builtin_bit_cast(b8, f), acc[tb + dx], 0, 0, 0);
+            else
+              acc[tb + dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(h8, f), acc[tb + dx], 0, 0, 0);
           }
+          __builtin_amdgcn_sched_barrier(0);             // nothing beyond window i+1 is hoisted above these MFMAs
+          cur = nxt; af_m = nm; af_o = no;
         }
       }
       WT_ADD(tc, tmark);
@@ -364,29 +387,39 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
     }
   }
 
-  // ---- epilogue: the KG k-step waves of a channel block are summed through LDS (three taps at a time), then the partial sums of this
-  // (run, pair) go to the scratch tensor part[run][tap][co][ci] with plain coalesced stores (lane = ci): no atomics, bitwise reproducible
+  // ---- epilogue: a tap row's partial sums sit in several waves of the channel block (row 0 in the even waves, row 2 in the odd ones,
+  // row 1 in all of them): one row at a time they are added up in LDS in wave order, then the row's three taps go to the scratch tensor
+  // part[run][tap][co][ci] with plain coalesced stores (lane = ci) -- no atomics, a fixed order: bitwise reproducible.
   __syncthreads();
   float* const red = reinterpret_cast<float*>(smem) + cw * (3 * 16 * 64);
+  const int cop = a.ncob * 32, cip = a.ncib * 32;
+  // D[i = co][j = ci]: lane = ci (l31), register r -> co = (r&3) + 8*(r>>2) + 4*lhi
+  float* const part = a.dw + (size_t)runi * 9 * cop * cip + (size_t)(cob * 32 + 4 * lhi) * cip + cib * 32 + l31;
+#pragma unroll
+  for (int row = 0; row < 3; ++row) {
+    const int tb = row == 1 ? 3 : 0;
 #pragma unroll 1
-  for (int kk = 1; kk < KG; ++kk) {
+    for (int j = 0; j < KG; ++j) {
+      const bool contributes = row == 1 || (j & 1) == (row >> 1);
+      const bool first = j == (row == 2 ? 1 : 0);
+      if (kg == j && contributes) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (kg == kk) {
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[c * 3 + j][r];
-      }
-      __syncthreads();
-      if (kg == 0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[c * 3 + j][r] += red[(j * 16 + r) * 64 + lane];
+          for (int r = 0; r < 16; ++r) {
+            float* const q = red + ((dx * 16 + r) * 64 + lane);
+            *q = first ? acc[tb + dx][r] : *q + acc[tb + dx][r];
+          }
       }
       __syncthreads();
     }
+    if (active) {
+      for (int dx = kg; dx < 3; dx += KG) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((size_t)(row * 3 + dx) * cop + (r & 3) + 8 * (r >> 2)) * cip] = red[(dx * 16 + r) * 64 + lane];
+      }
+    }
+    __syncthreads();
   }
 #ifdef VIRNET_F16_TIMING
   if (a.tlog && tid == 0) {
@@ -401,14 +434,6 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
     if (wv == 0) a.tlog[(size_t)blockIdx.x * 8 + 7] = ((long long)(xcc & 0xf) << 16) | (hw & 0xffff);
   }
 #endif
-  if (!active || kg != 0) return;
-  // D[i = co][j = ci]: lane = ci (l31), register r -> co = (r&3) + 8*(r>>2) + 4*lhi
-  const int cop = a.ncob * 32, cip = a.ncib * 32;
-  float* const part = a.dw + (size_t)runi * 9 * cop * cip + (size_t)(cob * 32 + 4 * lhi) * cip + cib * 32 + l31;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[((size_t)t * cop + (r & 3) + 8 * (r >> 2)) * cip] = acc[t][r];
 }
 
 // dw[co][ci][t] = sum over runs of part[run][t][co][ci]   (thread = one (t, co, ci); consecutive threads = consecutive ci).
