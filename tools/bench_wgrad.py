@@ -11,6 +11,8 @@ from virnet_amd import ops  # noqa: E402
 for name, (n, h, w, c) in {"l0": (32, 128, 128, 96), "l1": (32, 64, 64, 192), "l2": (32, 32, 32, 288)}.items():
     x = torch.rand(n, h, w, c, device="cuda") - 0.5
     dy = torch.rand(n, h, w, c, device="cuda") - 0.5
+    if os.environ.get("BENCH_ZEROS") == "1":                # power probe: all-zero operands toggle nothing in the matrix pipe
+        x.zero_(); dy.zero_()
     for _ in range(3):
         ops.conv_wgrad(x, dy, (c, c, 3, 3), in_slope=0.2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -331,22 +331,24 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
         // one lane-dependent LDS offset for both operands; everything else is a scalar (slot / stage / plane) plus an immediate
         // (lane16 = lhi * 512 + l31 * 16 is also this lane's fragment offset inside a row / dY image; the k-step adds kg * 1024.)
         // The scalar parts are re-derived per read (opaque to CSE): hoisted per-row addresses would cost seven live registers.
-        const unsigned ybs = RING * XROW + ((t - t0) % STAGES) * YST + cw * YW;
-        // Nine windows per step = 3 operand phases (dy_lo * a_hi, dy_hi * a_hi, dy_hi * a_lo; bf16: one) x [(own k-step, row r0),
-        // (own k-step, row 1), (partner k-step, row r0)].  A window = segment 1 + 2k + lhi of its row; xb points ONE segment earlier so
-        // that the three reads (last dword of the previous segment, the segment, first dword of the next) use non-negative
-        // immediates.  Window i+1 and the next phase's dY fragments are requested before the MFMAs of window i are issued.
+        // A SIMD issues ONE instruction per ~4 cycles over all its waves: a 32-cycle MFMA leaves room for at most seven others
+        // (MI355X_MICROARCH.md), so the loop is written for instruction COUNT.  The addresses of a step's windows are two VGPRs per
+        // tap row set up once per step (row slot of the ring + this lane's fragment offset, for the own and the partner k-step);
+        // planes, segments and the edge dwords are immediates off them: the base sits 4 bytes into the segment BEFORE the window, so
+        // ds_read2_b32 reaches the two edge dwords (bytes 12 and 1024 of that segment: dword offsets 2 and 255) and ds_read_b128 the
+        // window (byte 512 = offset 508).
+        const unsigned slot0 = ((ccnt + r0) % RING) * XROW, slot1 = ((ccnt + 1) % RING) * XROW;
+        const unsigned wa_m0 = lane16 + slot0 + km * 1024 + 4;      // (own k-step, row r0)
+        const unsigned wa_m1 = lane16 + slot1 + km * 1024 + 4;      // (own k-step, row 1)
+        const unsigned wa_o0 = lane16 + slot0 + ko * 1024 + 4;      // (partner k-step, row r0)
+        const unsigned ya = lane16 + RING * XROW + ((t - t0) % STAGES) * YST + cw * YW;
         struct Win { u32x4 d; unsigned dm, dp; };
         auto load_win = [&](int ph, int i) -> Win {
-          unsigned so_x = ((ccnt + (i == 1 ? 1 : r0)) % RING) * XROW + (ph == 2 ? XPL : 0) + (i == 2 ? ko : km) * 1024;
-          asm volatile("" : "+s"(so_x));
-          const char* const xb = smem + (lane16 + so_x);
-          return Win{*reinterpret_cast<const u32x4*>(xb + 512), *reinterpret_cast<const unsigned*>(xb + 12), *reinterpret_cast<const unsigned*>(xb + 1024)};
+          const char* const xb = smem + (i == 0 ? wa_m0 : i == 1 ? wa_m1 : wa_o0) + (ph == 2 ? XPL : 0);
+          return Win{*reinterpret_cast<const u32x4*>(xb + 508), *reinterpret_cast<const unsigned*>(xb + 8), *reinterpret_cast<const unsigned*>(xb + 1020)};
         };
         auto load_af = [&](int ph, int k) -> h8 {
-          unsigned so_y = ybs + ((!BF && ph == 0) ? YPL : 0) + k * 1024;
-          asm volatile("" : "+s"(so_y));
-          return *reinterpret_cast<const h8*>(smem + (lane16 + so_y));
+          return *reinterpret_cast<const h8*>(smem + ya + ((!BF && ph == 0) ? YPL : 0) + k * 1024);
         };
         constexpr int NPH = BF ? 1 : 3;
         h8 af_m = load_af(0, km), af_o = load_af(0, ko);
