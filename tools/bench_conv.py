@@ -49,6 +49,10 @@ def main():
         cp = ConvParam(c, c, 3).cuda()
         x = torch.rand(n, h, w, c, device="cuda") - 0.5
         res = torch.rand(n, h, w, c, device="cuda") - 0.5
+        if os.environ.get("BENCH_ZEROS") == "1":            # power probe: zero activations AND weights -> nothing toggles in the multipliers
+            x.zero_(); res.zero_()
+            with torch.no_grad():
+                cp.weight.zero_(); cp.bias.zero_()
         kw = {"dual": dict(res=res, want_raw=True, want_act=True), "act": dict(want_raw=False, want_act=True),
               "raw": dict(want_raw=True, want_act=False), "res": dict(res=res, want_raw=True),          # conv2 of a res-block
               "pre": dict(in_slope=0.2, want_raw=False, want_act=True)}[args.mode]                       # conv1 of a res-block
