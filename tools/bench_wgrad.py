@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the weight-gradient kernel on the denoise-syn shapes at the training batch (32 x 128x128)."""
+"""Micro-benchmark of the weight-gradient path (re-layout passes + GEMM + reduce) on the denoise-syn shapes at the training batch
+(32 x 128x128).  VIRNET_WGRAD_FORM=f32 times the round-1 fp32 kernel, VIRNET_CONV_FORM=bf16 the one-product variant, BENCH_ZEROS=1 the
+same launches on all-zero operands (power probe: nothing toggles in the multipliers)."""
 import os
 import sys
 
