@@ -7,6 +7,7 @@ run of the same network.  The emulations are exact models of what the matrix pip
   f32        plain fp32 (what v_mfma_f32_32x32x2_f32 computes; the direct kernel)
   wino2      Winograd F(2x2,3x3), fp32 transforms and products (the shipped kernel form)
   wino4      Winograd F(4x4,3x3), fp32 (36/144 multiplies; Lavin & Gray matrices)
+  wino2_f16x3 / wino4_f16x3   the same with the position products on the f16 pipe (split operands, three products)
   bf16x3     operands split x = hi + lo in bf16; products hi*hi + hi*lo + lo*hi accumulated in fp32
   bf16x6     three-way bf16 split, the six products of order <= 2^-16
   f16x3      operands split in fp16 (weights pre-scaled by a power of two per layer); hi*hi + hi*lo + lo*hi in fp32
@@ -77,8 +78,10 @@ def wino_mats(m):
     return BT, G, AT
 
 
-def conv_wino(x, w, m):
-    """F(m x m, 3x3) with every step in fp32 (weights transformed in fp64 then rounded once, as the packing kernel does)."""
+def conv_wino(x, w, m, split=False):
+    """F(m x m, 3x3) with every step in fp32 (weights transformed in fp64 then rounded once, as the packing kernel does).
+    ``split``: the position products on the f16 pipe with split operands (U pre-scaled by a power of two), as conv_f16 does for the
+    direct form -- the candidate that executes 3*16/36 FLOPs per algorithmic FLOP."""
     BT, G, AT = wino_mats(m)
     a = m + 2
     n, c, h, wd = x.shape
@@ -89,7 +92,13 @@ def conv_wino(x, w, m):
     BTf, ATf = BT.float(), AT.float()
     V = torch.einsum("ij,nctujk,lk->nctuil", BTf, tiles, BTf)         # fp32 transform
     U = torch.einsum("ij,ocjk,lk->ocil", G, w.double(), G).float()    # [co, c, a, a]
-    M = torch.einsum("ocil,nctuil->notuil", U, V)                     # fp32 products / accumulation
+    if split:
+        sc = pow2_scale(U)
+        (uh, ul), (vh, vl) = split_f16(U * sc, 2), split_f16(V, 2)
+        M = (torch.einsum("ocil,nctuil->notuil", ul, vh) + torch.einsum("ocil,nctuil->notuil", uh, vl)
+             + torch.einsum("ocil,nctuil->notuil", uh, vh)) * (1.0 / sc)
+    else:
+        M = torch.einsum("ocil,nctuil->notuil", U, V)                 # fp32 products / accumulation
     Y = torch.einsum("ij,notujk,lk->notuil", ATf, M, ATf)             # [n, co, th, tw, m, m]
     th, tw = Y.shape[2], Y.shape[3]
     y = Y.permute(0, 1, 2, 4, 3, 5).reshape(n, co, th * m, tw * m)
@@ -101,8 +110,8 @@ def make_conv(mode):
         elig = (stride == 1 and w.shape[-1] == 3 and w.shape[1] >= 32 and w.shape[0] % 32 == 0 and x.dtype == torch.float32)
         if not elig or mode == "f32":
             return _REAL_CONV(x, w, b, stride, padding, *a, **k)
-        if mode in ("wino2", "wino4"):
-            y = conv_wino(x, w, 2 if mode == "wino2" else 4)
+        if mode in ("wino2", "wino4", "wino2_f16x3", "wino4_f16x3"):
+            y = conv_wino(x, w, 2 if mode.startswith("wino2") else 4, split=mode.endswith("f16x3"))
         elif mode in ("bf16x3", "bf16x6"):
             parts = 2 if mode == "bf16x3" else 3
             xs, ws = split_bf16(x, parts), split_bf16(w, parts)
