@@ -152,6 +152,21 @@ size_t virnet_f16_convt_weight_floats(int cin, int cout);
 int virnet_pack_f16_convt_weight(const float* w_iohw, int cout, int cin, float* packed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The same stride-1 3x3 NHWC convolution in Winograd F(4,3) form ALONG X (direct along y) on the f16 matrix pipe with split fp32
+ * operands (csrc/conv_f16_wx4.hip): 6 transform positions x 3 row taps = 18 k-steps per 4 output pixels instead of 36, i.e. 1.5
+ * executed FLOP per algorithmic FLOP instead of conv_f16's 3, same three-product fp32-class arithmetic per position product.
+ * Call sites as virnet_conv_f16: AttResBlock.conv1/conv2 (AttResUNet.py:55,58 + residual :59), DnCNN mid_layer (DnCNN.py:25-28,39-40)
+ * and their input-gradient GEMMs.  SAME descriptor (ks = 3, stride = 1, epi = VIRNET_EPI_NHWC, cout % 32 == 0, n_pad = cout) with
+ * `wpack` from virnet_pack_wx4_weight: n_pad inverse row scales followed by U[dy][j] = sum_b G[j][b] w[dy][b] (formed in fp64) as
+ * the split image [n_pad/32][cin_pad/16][6 positions][3 dy][hi|lo][64 lanes][8 x fp16].  Accuracy: the Winograd transform adds
+ * rounding relative to the largest magnitude inside a 6-pixel input window (not per output): whole denoise-syn network 1.1e-5 max-abs
+ * against fp64 (conv_f16 8.0e-6, fp32 direct 8.9e-6).  Transformed activations must stay below 65504 (|x| < 6.5e3).
+ * ---------------------------------------------------------------------------------------------- */
+size_t virnet_wx4_weight_floats(int cin_pad, int n_pad);
+int virnet_pack_wx4_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
+int virnet_conv_wx4(const virnet_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):
  * AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173), DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43),
  * KernelNet.tail conv (KNet.py:49).  Weights: virnet_pack_thin_weight of the OIHW tensor.

@@ -527,6 +527,7 @@ __global__ void pack_f16_kernel(const float* __restrict__ w, int kind, int cout,
 #ifdef VIRNET_F16_TIMING
 static long long* g_tlog = nullptr;
 extern "C" void virnet_debug_timing_buffer(void* p) { g_tlog = static_cast<long long*>(p); }
+long long* virnet_f16_tlog() { return g_tlog; }
 #endif
 
 extern "C" size_t virnet_f16_weight_floats(int cin_pad, int n_pad) { return (size_t)n_pad + (size_t)n_pad * cin_pad * 9; }

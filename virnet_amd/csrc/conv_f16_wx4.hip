@@ -1,0 +1,556 @@
+// conv_f16_wx4.hip -- the stride-1 3x3 convolution in Winograd F(4,3) form ALONG X (direct along y) on the CDNA4 f16 matrix pipe
+// with SPLIT fp32 operands (gfx950).
+//
+// Same call sites as conv_f16.hip (AttResBlock.conv1/conv2, networks/AttResUNet.py:43,46,55,58; DnCNN mid convs, networks/DnCNN.py:25-28)
+// and their input-gradient GEMMs.  Same arithmetic for every product (conv_f16.hip: v = hi + lo in fp16, three v_mfma_f32_32x32x16_f16
+// per fp32 product, fp32 accumulation), but half of the products:
+//
+//   out[y][4t + k] = sum_j AT[k][j] * M_j[y][t],     M_j[y][t] = sum_dy sum_ci U[dy][j][co][ci] * V_j[y + dy - 1][t][ci]
+//   U[dy][j] = sum_b G[j][b] w[dy][b]   (weights, transformed in fp64 when they are packed)
+//   V_j[r][t] = sum_i BT[j][i] x[r][4t - 1 + i]   (6 input pixels -> 6 positions per 4-pixel x-tile, formed in fp32 while staging)
+//
+// i.e. 6 positions x 3 row taps = 18 MFMA k-steps per 4 output pixels instead of 36: 1.5 executed FLOP per algorithmic FLOP on the
+// f16 pipe instead of 3.  Why 1-D and not F(2x2,3x3): the row taps accumulate into the SAME position accumulator, so a tile costs 6
+// accumulators per 4 pixels (2-D F(2x2): 16 per 4) and a CU's register file holds a 16x32 pixel tile x 96 channels -- the transformed
+// weights are then re-read from L2 once per 512 pixels (21 B/clk/CU at the pipe's peak; the 2-D form needs 43-85 B/clk/CU, more than the
+// L2->LDS path delivers), and the input transform costs 1.8 VALU ops per MFMA instead of 3.6.  Numerics (tools/numerics_gate.py, whole
+// denoise-syn network against fp64): 1.13e-5 max-abs on mu (fp32 direct 8.9e-6, 2-D F(2x2) 8.7e-6, 2-D F(4x4) 2.6e-5).
+//
+// Workgroup = 8 waves = one 16 x 32 pixel tile x 32*NREP output channels; wave (jt, rb) owns positions {3jt, 3jt+1, 3jt+2} of row
+// block rb (4 rows x 8 x-tiles = the 32 columns of an MFMA): 3 x NREP accumulator blocks.  One workgroup per CU (LDS).
+//   V (LDS, 54 KB): per position a hi and a lo plane of [18 rows][8 x-tiles] 32-byte records (16 fp16 channels), slot swizzle by row
+//       parity -> conflict-free ds_read_b128 B fragments.  SINGLE buffered, replaced on the fly: a K chunk is walked as three stages
+//       ji = 0,1,2 in which every wave works on position 3jt + ji, so planes {ji, 3+ji} are dead after stage ji and the threads write
+//       the NEXT chunk's values into them during the following stage (raw pixels are held in registers across the three stages).
+//   U (LDS, 2 x 12*NREP KB): stage = positions {ji, 3+ji} x 3 row taps x NREP slabs x (hi|lo) fragments of 1 KB, streamed by DMA
+//       (global_load_lds_dwordx4) one stage ahead, double buffered; one barrier per stage (9*NREP MFMAs per wave).
+//   Staging: thread = (row, x-tile, channel quad); the tile's 18 V rows are 9 wave-items for 8 waves -- the two halo rows are a second
+//       item of ONE wave, rotating with the chunk.
+// Epilogue: the inverse transform crosses the two waves of a row block, so per 32-channel slab every wave writes three pre-combined
+// blocks ([pixel][channel] records) to LDS and each thread finishes (pixel, channel quad) items from two or three of them: the same
+// round trip also turns the tile around for 128-byte runs in the NHWC store.  Inverse scale, bias, mask, residual, activation as conv_f16.hip.
+#include "conv_f16_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+using namespace virnet;
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int WX_PLANE = 18 * 8 * 32;        // one (position, hi|lo) plane: [18 rows][8 x-tiles][32 B]
+constexpr int WX_POS = 2 * WX_PLANE;
+constexpr int WX_VBYTES = 6 * WX_POS;        // 55296
+constexpr int WX_XBLK = 32 * 144 + 64;       // exchange block: [32 columns][32 channels + 16 B pad], skewed by 64 B against its neighbours
+constexpr int WX_CHUNK_BYTES = 36 * 1024;    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
+
+template <int J>
+__device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
+  // rows of BT (Lavin & Gray, F(4,3), points 0, +-1, +-2, inf)
+  if constexpr (J == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
+  if constexpr (J == 1) return (d[4] - 4.f * d[2]) + (d[3] - 4.f * d[1]);
+  if constexpr (J == 2) return (d[4] - 4.f * d[2]) - (d[3] - 4.f * d[1]);
+  if constexpr (J == 3) return (d[4] - d[2]) + 2.f * (d[3] - d[1]);
+  if constexpr (J == 4) return (d[4] - d[2]) - 2.f * (d[3] - d[1]);
+  return 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+struct WxItem {
+  unsigned off[6];   // element offsets of the six input pixels (clamped into the image), channel quad included
+  unsigned inb;      // bit b: pixel b lies inside the image
+  int dst;           // byte offset of this (row, x-tile, quad) inside a V plane
+};
+
+template <int NREP, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
+  constexpr int NB = 32 * NREP;
+  constexpr int NDMA = 12 * NREP;                  // 1-KB pieces of one weight stage: [jt][dy][slab][hi|lo]
+  constexpr int USTAGE = NDMA * 1024;
+  constexpr int NDI = (NDMA + 7) / 8;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const v_lds = smem;
+  char* const w_lds = smem + WX_VBYTES;
+
+  // ---- workgroup -> (tile, channel block): contiguous tile ranges per XCD (block b runs on XCD b%8), channel blocks adjacent
+  const int ncb = a.NP / NB;
+  const int xcd = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int cb = __builtin_amdgcn_readfirstlane(q % ncb);
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + q / ncb);
+  if (q / ncb >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int tx = __builtin_amdgcn_readfirstlane(tile % a.ntx);
+  const int ty = __builtin_amdgcn_readfirstlane((tile / a.ntx) % a.nty);
+  const int img = __builtin_amdgcn_readfirstlane(tile / (a.ntx * a.nty));
+  const int oy0 = ty * 16, ox0 = tx * 32;
+
+  const int tid = threadIdx.x;
+  TSTAMP(0);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int jt = wave & 1, rb = wave >> 1;
+  const int nch = a.Cin >> 4;
+  const int nstages = nch * 3;
+  const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
+
+  // ---- staging items: (V row, x-tile, channel quad); item 0 = rows 0..15 (every thread), item 1 = rows 16,17 (one wave per chunk)
+  const int sxt = (lane >> 2) & 7, sq = lane & 3;
+  auto make_item = [&](int srow) {
+    WxItem it;
+    const int gy = oy0 - 1 + srow;
+    const bool rin = (unsigned)gy < (unsigned)a.H;
+    const int gyc = min(max(gy, 0), a.H - 1);
+    it.inb = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int gx = ox0 - 1 + 4 * sxt + b;
+      const bool in = rin && (unsigned)gx < (unsigned)a.W;
+      const int gxc = min(max(gx, 0), a.W - 1);
+      it.off[b] = (unsigned)((gyc * a.W + gxc) * a.Cin + 4 * sq);
+      it.inb |= (in ? 1u : 0u) << b;
+    }
+    it.dst = (srow * 8 + sxt) * 32 + ((((sq >> 1) ^ (srow & 1))) << 4) + (sq & 1) * 8;
+    return it;
+  };
+  const WxItem it0 = make_item(tid >> 5);
+  const WxItem it1 = make_item(16 + (lane >> 5));
+  const bool in_sft = a.in_mul != nullptr;
+  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + 4 * sq : nullptr;
+  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + 4 * sq : nullptr;
+  const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  auto load_raw = [&](f32x4 (&d)[6], const WxItem& it, int chunk) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const f32x4*>(ximg + it.off[b] + chunk * 16);
+  };
+  // pre-activation (AttResUNet.py:54-55: lrelu(x*mul+add)), zero outside the image AFTER it
+  auto preact = [&](f32x4 (&d)[6], const WxItem& it, int chunk) {
+    f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f}, ad = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (in_sft) {
+      m = *reinterpret_cast<const f32x4*>(imul + chunk * 16);
+      ad = *reinterpret_cast<const f32x4*>(iadd + chunk * 16);
+    }
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      f32x4 v = d[b];
+      if (in_sft) v = v * m + ad;
+      v = lrelu4(v, in_slope_eff);
+      d[b] = ((it.inb >> b) & 1u) ? v : z;
+    }
+  };
+  auto put = [&](auto jc, const f32x4 (&d)[6], const WxItem& it) {
+    constexpr int J = decltype(jc)::value;
+    const f32x4 v = wx4_pos<J>(d);
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (_Float16)v[e];
+      lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    *reinterpret_cast<h4*>(v_lds + J * WX_POS + it.dst) = hi;
+    *reinterpret_cast<h4*>(v_lds + J * WX_POS + WX_PLANE + it.dst) = lo;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+  using I5 = std::integral_constant<int, 5>;
+
+  // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB]
+  const size_t slab_bytes = (size_t)nch * WX_CHUNK_BYTES;
+  const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes + lane * 16;
+  int poff[NDI];
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) {
+    const int qd = min(i * 8 + wave, NDMA - 1);
+    const int jq = qd / (6 * NREP), r = qd - jq * (6 * NREP);
+    const int dq = r / (2 * NREP), r2 = r - dq * (2 * NREP);
+    poff[i] = __builtin_amdgcn_readfirstlane((r2 >> 1) * (int)slab_bytes + jq * (3 * 3 * 2048) + dq * 2048 + (r2 & 1) * 1024);
+  }
+  auto dma_stage = [&](int src_off, char* wb) {            // src_off = chunk * 36 KB + ji * 6 KB
+#pragma unroll
+    for (int i = 0; i < NDI; ++i) {
+      const int qd = i * 8 + wave;
+      if (qd < NDMA) {
+        const char* src = wcb + src_off + poff[i];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(wb + qd * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- fragment addressing
+  int boff[3];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int row = 4 * rb + dy + (l31 >> 3);
+    boff[dy] = ((4 * rb + dy) * 8 + l31) * 32 + ((lhi ^ (row & 1)) << 4);
+  }
+  const int a_base = jt * (3 * NREP * 2048) + lane * 16;
+  const char* const vjt = v_lds + jt * 3 * WX_POS;
+
+  f32x16 acc[3][NREP];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][nr][r] = 0.f;
+
+  // ---- prologue: weights of stage 0 by DMA; chunk 0's pixels -> positions {0,3} and {1,4} ({2,5} are written by stage 0 itself)
+  dma_stage(0, w_lds);
+  f32x4 d0[6], d1[6];
+  load_raw(d0, it0, 0);
+  if (wave == 0) load_raw(d1, it1, 0);
+  preact(d0, it0, 0);
+  put(I0{}, d0, it0); put(I3{}, d0, it0); put(I1{}, d0, it0); put(I4{}, d0, it0);
+  if (wave == 0) {
+    preact(d1, it1, 0);
+    put(I0{}, d1, it1); put(I3{}, d1, it1); put(I1{}, d1, it1); put(I4{}, d1, it1);
+  }
+  __syncthreads();
+  TSTAMP(1);
+
+  // One stage = positions {ji, 3+ji} of chunk c.  d0 / d1 hold the (pre-activated from stage 1 on) pixels of chunk `cd`: the chunk
+  // whose V planes are being written -- c itself in stage 0, c+1 in stages 1 and 2 (the last chunk rewrites its own dead planes).
+  auto stage = [&](int c, auto jic) {
+    constexpr int ji = decltype(jic)::value;
+    const int s = c * 3 + ji;
+    const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
+    char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
+    if (s + 1 < nstages) dma_stage(ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : (c + 1) * WX_CHUNK_BYTES, wn);
+    const int cn = min(c + 1, nch - 1);
+    if constexpr (ji == 0) {
+      put(I2{}, d0, it0); put(I5{}, d0, it0);
+      if (wave == (c & 7)) { put(I2{}, d1, it1); put(I5{}, d1, it1); }
+      load_raw(d0, it0, cn);
+      if (wave == (cn & 7)) load_raw(d1, it1, cn);
+    } else if constexpr (ji == 1) {
+      preact(d0, it0, cn);
+      put(I0{}, d0, it0); put(I3{}, d0, it0);
+      if (wave == (cn & 7)) { preact(d1, it1, cn); put(I0{}, d1, it1); put(I3{}, d1, it1); }
+    } else {
+      put(I1{}, d0, it0); put(I4{}, d0, it0);
+      if (wave == (cn & 7)) { put(I1{}, d1, it1); put(I4{}, d1, it1); }
+    }
+    const char* const vb = vjt + ji * WX_POS;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const h8 bh = *reinterpret_cast<const h8*>(vb + boff[dy]);
+      const h8 bl = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
+#pragma unroll
+      for (int nr = 0; nr < NREP; ++nr) {
+        const h8 ah = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 0) * 1024);
+        const h8 al = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 1) * 1024);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ji][nr], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  for (int c = 0; c < nch; ++c) {
+    stage(c, I0{});
+    stage(c, I1{});
+    stage(c, I2{});
+  }
+  TSTAMP(2);
+
+  // ---- epilogue.  Per slab: wave (jt, rb) writes three blocks of [column = (row, x-tile)][32 channels] records
+  //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
+  // and pixel k of an x-tile is  k=0: A0 + S   k=1: A1 + 2D   k=2: A2 + 4S   k=3: A1 + 8D + E   (rows of AT).
+  char* const xb = smem;
+  const int wblk = (rb * 6 + jt * 3) * WX_XBLK + l31 * 144 + lhi * 16;
+  auto put_block = [&](int which, const f32x16& m) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(xb + wblk + which * WX_XBLK + g * 32) = f32x4{m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]};
+  };
+  auto xwrite = [&](int nr) {
+    f32x16 b0, b1, b2;
+    if (jt == 0) {
+      b2 = acc[1][nr] + acc[2][nr];
+      b1 = acc[1][nr] - acc[2][nr];
+      b0 = acc[0][nr] + b2;
+    } else {
+      b0 = acc[0][nr] + acc[1][nr];
+      b1 = acc[0][nr] - acc[1][nr];
+      b2 = acc[2][nr];
+    }
+    put_block(0, b0); put_block(1, b1); put_block(2, b2);
+  };
+  // reader: thread = (pixel column x of the tile, channel quad cq), items it = row pairs
+  constexpr int NIT = 8;
+  const int cq = tid & 7, px = (tid >> 3) & 31, prow = tid >> 8;
+  const int pk = px & 3, pxt = px >> 2;
+  const int r_p = ((pk == 0) ? 0 : (pk == 2) ? 2 : 1) * WX_XBLK + pxt * 144 + cq * 16;
+  const int r_q = (3 + (pk & 1)) * WX_XBLK + pxt * 144 + cq * 16;
+  const int r_e = 5 * WX_XBLK + pxt * 144 + cq * 16;
+  const float ck = (float)(1 << pk), ek = pk == 3 ? 1.f : 0.f;
+  auto xread = [&](int it) {                                // row = 2*it + prow: row block it>>1, row-in-block (it&1)*2 + prow
+    const int base = (it >> 1) * 6 * WX_XBLK + (((it & 1) * 2 + prow) * 8) * 144;
+    const f32x4 p = *reinterpret_cast<const f32x4*>(xb + base + r_p);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + base + r_q);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(xb + base + r_e);
+    return p + ck * qv + ek * e;
+  };
+  const int nbase = a.slab_base * 32 + cb * NB;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int C = a.cout;
+  const size_t img_off = (size_t)img * a.H * a.W * C;
+  unsigned eoff[NIT];
+  bool eok[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int oy = oy0 + 2 * it + prow, ox = ox0 + px;
+    eok[it] = oy < a.H && ox < a.W;
+    eoff[it] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)(nbase + cq * 4);
+  }
+  auto mask4 = [&](f32x4 v, f32x4 m) {
+    return f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
+                 m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
+  };
+  if constexpr (EPI < 4) {
+    // ONE stored tensor.  Every global load of the tile is requested before the first store (conv_f16.hip: loads and stores share one
+    // counter that must be treated as out of order once both kinds are pending); EPI 3 cannot hold two operand tiles and loads per slab.
+    constexpr bool RES = (EPI & 1) != 0, MASK = (EPI & 2) != 0;
+    const float* const rimg = a.res + img_off;
+    const float* const mimg = a.mask + img_off;
+    float* const y = (a.y_act ? a.y_act : a.y_raw) + img_off;
+    const float slope_eff = a.y_act ? a.slope : 1.f;
+    const float* const bp = a.bias ? a.bias : a.inv_scale;
+    const float hb = a.bias ? 1.f : 0.f;
+    constexpr bool HOIST = EPI == 1 || EPI == 2;
+    f32x4 bias4[NREP], inv4[NREP], op1[HOIST ? NREP : 1][NIT];
+    const float* const op1p = RES ? rimg : mimg;
+    xwrite(0);
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nbase + nr * 32 + cq * 4);
+      bias4[nr] = *reinterpret_cast<const f32x4*>(bp + nbase + nr * 32 + cq * 4);
+      if (HOIST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) op1[nr][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      asm volatile("" ::"v"(inv4[nr]), "v"(bias4[nr]));
+      if (HOIST) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" ::"v"(op1[nr][it]));
+      }
+    }
+#endif
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
+    unsigned yoff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) yoff[it] = eok[it] ? eoff[it] * 4u : 0x80000000u;
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      if (nr > 0) xwrite(nr);
+      __syncthreads();
+      f32x4 mv[NIT], rv[NIT];
+      if (EPI == 3) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          mv[it] = *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32);
+          rv[it] = *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
+        }
+      }
+      const f32x4 b4 = bias4[nr] * hb;
+      f32x4 tv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) tv[it] = xread(it);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 v = tv[it] * inv4[nr] + b4;
+        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[HOIST ? nr : 0][it]);
+        if (RES) v += EPI == 3 ? rv[it] : op1[HOIST ? nr : 0][it];
+        v = lrelu4(v, slope_eff);
+        // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
+      }
+      if (nr + 1 < NREP) __syncthreads();
+    }
+  } else {
+    // generic form (two stored tensors and / or SFT on the output): optional operands by runtime pointer
+    const float* const rimg = a.res ? a.res + img_off : nullptr;
+    const float* const mimg = a.mask ? a.mask + img_off : nullptr;
+    float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
+    float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) {
+      xwrite(nr);
+      __syncthreads();
+      const int co = nbase + nr * 32 + cq * 4;
+      const f32x4 inv4 = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
+      const f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
+      f32x4 mul4 = f32x4{1.f, 1.f, 1.f, 1.f}, add4 = zero4;
+      if (a.mul) {                                           // SFT on the output (AttResUNet.py:57-58): SISR down path
+        mul4 = *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + co);
+        add4 = *reinterpret_cast<const f32x4*>(a.add + (size_t)img * C + co);
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 v = xread(it) * inv4 + bias4;
+        if (eok[it]) {
+          if (mimg) v = mask4(v, *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32));
+          if (rimg) v += *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
+          if (yraw) *reinterpret_cast<f32x4*>(yraw + eoff[it] + nr * 32) = v;
+          if (yact) *reinterpret_cast<f32x4*>(yact + eoff[it] + nr * 32) = lrelu4(v * mul4 + add4, a.slope);
+        }
+      }
+      if (nr + 1 < NREP) __syncthreads();
+    }
+  }
+  TSTAMP(3);
+}
+
+template <int NREP, int EPI>
+int launch_wx4(FArgs k, hipStream_t st) {
+  constexpr int LDS_K = WX_VBYTES + 2 * 12 * NREP * 1024;
+  constexpr int LDS_E = 24 * WX_XBLK;
+  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
+  static_assert(LDS <= 160 * 1024, "one workgroup per CU");
+  static unsigned long long attr_done = 0;
+  auto kern = conv_wx4_kernel<NREP, EPI>;
+  if (virnet::first_use_on_device(attr_done)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wx4): %s", hipGetErrorString(e));
+  }
+  k.nty = (k.H + 15) / 16;
+  k.ntx = (k.W + 31) / 32;
+  k.ntiles = k.N * k.nty * k.ntx;
+  k.tiles_per_xcd = (k.ntiles + 7) / 8;
+  const int ncb = k.NP / (32 * NREP);
+  const unsigned grid = (unsigned)(8 * k.tiles_per_xcd * ncb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, k);
+  return virnet::check_launch("conv_wx4 launch");
+}
+
+// ---- weight packing ---------------------------------------------------------------------------------------------------------
+// One block per GEMM row (output channel).  U[dy][j] = sum_b G[j][b] w[dy][b] in fp64, one power-of-two scale per row from the
+// largest |U|, then the split image [slab][chunk][position j][dy][hi|lo][lane][8 x fp16] (lane / element order = the A fragment of
+// v_mfma_f32_32x32x16_f16, as conv_f16.hip).  kind 0: forward OIHW; kind 2: the input-gradient GEMM (rows = forward cin, flipped taps).
+__global__ void pack_wx4_kernel(const float* __restrict__ w, int kind, int cout, int cin, int cin_pad, int n_pad,
+                                float* __restrict__ inv_scale, char* __restrict__ img) {
+  const int row = blockIdx.x;
+  const int rows = kind == 2 ? cin : cout, ks = kind == 2 ? cout : cin;
+  const int nch = cin_pad >> 4;
+  auto wval = [&](int k, int dy, int dx) -> double {
+    if (row >= rows || k >= ks) return 0.0;
+    return kind == 2 ? (double)w[(((size_t)k * cin + row) * 3 + (2 - dy)) * 3 + (2 - dx)] : (double)w[(((size_t)row * cin + k) * 3 + dy) * 3 + dx];
+  };
+  auto uval = [&](int k, int dy, int j) -> double {
+    const double g0 = wval(k, dy, 0), g1 = wval(k, dy, 1), g2 = wval(k, dy, 2);
+    switch (j) {
+      case 0: return g0 * 0.25;
+      case 1: return -(g0 + g1 + g2) / 6.0;
+      case 2: return (-g0 + g1 - g2) / 6.0;
+      case 3: return g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
+      case 4: return g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
+      default: return g2;
+    }
+  };
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < ks * 18; i += blockDim.x) m = fmaxf(m, fabsf((float)uval(i / 18, (i % 18) % 3, (i % 18) / 3)));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  int e = 0;
+  if (m > 0.f) { frexpf(m, &e); e = 14 - e; }        // largest scaled magnitude in [8192, 16384)
+  e = max(-100, min(100, e));
+  if (threadIdx.x == 0) inv_scale[row] = ldexpf(1.f, -e);
+  const int slab = row >> 5, col = row & 31;
+  for (int i = threadIdx.x; i < cin_pad * 18; i += blockDim.x) {
+    const int k = i / 18, t = i % 18, j = t / 3, dy = t % 3;
+    const float v = (float)ldexp(uval(k, dy, j), e);
+    const int chunk = k >> 4, kk = k & 15;
+    const size_t base = (((((size_t)slab * nch + chunk) * 6 + j) * 3 + dy) * 2) * 1024 + (size_t)(col + 32 * (kk >> 3)) * 16 + (kk & 7) * 2;
+    const _Float16 hi = (_Float16)v;
+    *reinterpret_cast<_Float16*>(img + base) = hi;
+    *reinterpret_cast<_Float16*>(img + base + 1024) = (_Float16)(v - (float)hi);
+  }
+}
+
+}  // namespace
+
+#ifdef VIRNET_F16_TIMING
+extern long long* virnet_f16_tlog();
+#endif
+
+extern "C" size_t virnet_wx4_weight_floats(int cin_pad, int n_pad) { return (size_t)n_pad + (size_t)n_pad * cin_pad * 18; }
+
+extern "C" int virnet_pack_wx4_weight(const float* w, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream) {
+  VIRNET_REQUIRE(w && packed, "virnet_pack_wx4_weight: NULL pointer");
+  VIRNET_REQUIRE(cout > 0 && cin > 0, "virnet_pack_wx4_weight: bad extents cout=%d cin=%d", cout, cin);
+  const int rows = dgrad ? cin : cout, ks = dgrad ? cout : cin;
+  VIRNET_REQUIRE(cin_pad % 16 == 0 && cin_pad >= ks, "virnet_pack_wx4_weight: cin_pad=%d does not cover %d contraction channels", cin_pad, ks);
+  VIRNET_REQUIRE(n_pad % 32 == 0 && n_pad >= rows, "virnet_pack_wx4_weight: n_pad=%d does not cover %d output channels", n_pad, rows);
+  hipLaunchKernelGGL(pack_wx4_kernel, dim3((unsigned)n_pad), dim3(256), 0, static_cast<hipStream_t>(stream), w, dgrad ? 2 : 0, cout, cin,
+                     cin_pad, n_pad, packed, reinterpret_cast<char*>(packed + n_pad));
+  return virnet::check_launch("pack_wx4 launch");
+}
+
+extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
+  VIRNET_REQUIRE(d != nullptr, "virnet_conv_wx4: desc is NULL");
+  VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_wx4: x / wpack is NULL");
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_wx4: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
+                 d->ks, d->stride, d->epi);
+  VIRNET_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, "virnet_conv_wx4: empty input n=%d h=%d w=%d", d->n, d->h, d->w);
+  VIRNET_REQUIRE(d->cin_pad >= 16 && d->cin_pad % 16 == 0, "virnet_conv_wx4: cin_pad=%d is not a multiple of 16", d->cin_pad);
+  VIRNET_REQUIRE(d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout, "virnet_conv_wx4: cout=%d must be a multiple of 32 (n_pad=%d)", d->cout, d->n_pad);
+  VIRNET_REQUIRE(d->y_raw || d->y_act, "virnet_conv_wx4: no output pointer");
+  VIRNET_REQUIRE((long)d->h * d->w * d->n_pad * 4 < (1L << 31), "virnet_conv_wx4: one image's output (%d x %d x %d fp32) must stay below 2 GB", d->h, d->w, d->n_pad);
+  VIRNET_REQUIRE((long)d->h * d->w * d->cin_pad * 4 < (1L << 31), "virnet_conv_wx4: one image's input (%d x %d x %d fp32) must stay below 2 GB", d->h, d->w, d->cin_pad);
+  VIRNET_REQUIRE((d->in_mul == nullptr) == (d->in_add == nullptr), "virnet_conv_wx4: in_mul and in_add must be given together");
+  VIRNET_REQUIRE(d->in_act || !d->in_mul, "virnet_conv_wx4: in_mul/in_add without in_act");
+  VIRNET_REQUIRE(!d->in_act || (d->in_slope >= 0.f && d->in_slope <= 1.f), "virnet_conv_wx4: in_slope=%g outside [0,1]", d->in_slope);
+  VIRNET_REQUIRE(!d->y_act || (d->slope >= 0.f && d->slope <= 1.f), "virnet_conv_wx4: slope=%g outside [0,1]", d->slope);
+  FArgs k{};
+  k.x = d->x; k.inv_scale = d->wpack; k.wimg = reinterpret_cast<const char*>(d->wpack + d->n_pad);
+  k.bias = d->bias; k.res = d->res; k.mul = d->mul; k.add = d->add;
+  k.in_mul = d->in_mul; k.in_add = d->in_add; k.mask = d->mask; k.y_raw = d->y_raw; k.y_act = d->y_act;
+  k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = d->cin_pad; k.NP = d->n_pad; k.cout = d->cout;
+  k.OH = d->h; k.OW = d->w;
+  k.in_act = d->in_act; k.in_slope = d->in_slope; k.mask_slope = d->mask_slope; k.slope = d->slope;
+#ifdef VIRNET_F16_TIMING
+  k.tlog = virnet_f16_tlog();
+#endif
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nb = d->n_pad / 32;
+  const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
+  // slabs per workgroup: 3 where the count allows, the remainder in 2s (160 = 3 + 2, 224 = 3 + 2 + 2), a lone odd slab by itself
+  int n3 = nb / 3, rem = nb - 3 * n3;
+  if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
+  const int n2 = rem / 2, n1 = rem - 2 * n2;
+  auto run = [&](int nrep, int slab_base, int groups) -> int {
+    if (groups <= 0) return 0;
+    FArgs kk = k;
+    kk.slab_base = slab_base;
+    kk.NP = groups * nrep * 32;
+#define VIRNET_WX4_CASE(N_)                                      \
+    if (nrep == N_) {                                            \
+      if (epi == 0) return launch_wx4<N_, 0>(kk, st);            \
+      if (epi == 1) return launch_wx4<N_, 1>(kk, st);            \
+      if (epi == 2) return launch_wx4<N_, 2>(kk, st);            \
+      if (epi == 3) return launch_wx4<N_, 3>(kk, st);            \
+      return launch_wx4<N_, 4>(kk, st);                          \
+    }
+    VIRNET_WX4_CASE(3) VIRNET_WX4_CASE(2) VIRNET_WX4_CASE(1)
+#undef VIRNET_WX4_CASE
+    return virnet::set_error("virnet_conv_wx4: no kernel for nrep=%d", nrep);
+  };
+  if (int rc = run(3, 0, n3)) return rc;
+  if (int rc = run(2, 3 * n3, n2)) return rc;
+  return run(1, 3 * n3 + 2 * n2, n1);
+}

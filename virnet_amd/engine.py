@@ -45,7 +45,7 @@ def _ceil_to(v: int, m: int) -> int:
 
 def _conv_planar(x: Tensor, conv, crop_hw, **kw) -> Tensor:
     """3x3 conv with planar (NCHW) store: the bandwidth-bound kernel for <= 4 output channels, the MFMA kernel otherwise."""
-    if ops.conv_form() in ("f16x3", "bf16") and conv.cout <= 32:
+    if ops._f16_family() and conv.cout <= 32:
         return ops.conv_f16_nchw(x, conv.packed(), crop_hw, **kw)          # split-fp16 kernel, one slab, planar store
     if conv.cout <= 4:
         return ops.conv3x3_thin(x, conv.packed_thin(), crop_hw, **kw)

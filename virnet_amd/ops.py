@@ -32,6 +32,7 @@ class PackedWeight:
     wino: Optional[Tensor] = None   # Winograd-domain image (virnet_pack_wino_weight) of a stride-1 3x3 layer, when eligible
     f16: Optional[Tensor] = None    # split-fp16 image (virnet_pack_f16_weight) of a stride-1 3x3 layer, when eligible
     bf16: Optional[Tensor] = None   # bf16-operand image (virnet_pack_bf16_weight) of a C->C stride-1 3x3 layer (form "bf16" only)
+    wx4: Optional[Tensor] = None    # Winograd F(4,3)-along-x split-fp16 image (virnet_pack_wx4_weight) of a C->C stride-1 3x3 layer (form "wx4")
 
 
 class LaunchTimer:
@@ -63,7 +64,8 @@ def set_launch_timer(t: Optional[LaunchTimer]) -> None:
 
 def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct") -> None:
     lib = nat.load()
-    fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "bf16": lib.virnet_conv_bf16, "direct": lib.virnet_conv_mfma}[form]
+    fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "bf16": lib.virnet_conv_bf16, "direct": lib.virnet_conv_mfma,
+          "wx4": lib.virnet_conv_wx4}[form]
     if _TIMER is None:
         nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
@@ -80,8 +82,10 @@ def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct
     _TIMER.records.append((key, flops, e0, e1))
 
 
-# Three forms of the stride-1 3x3 convolution whose channel counts fill MFMA blocks (read per call: tests flip it):
-#   VIRNET_CONV_FORM=f16x3   split-fp16 operands on the f16 matrix pipe (csrc/conv_f16.hip) -- the default
+# Forms of the stride-1 3x3 convolution whose channel counts fill MFMA blocks (read per call: tests flip it):
+#   VIRNET_CONV_FORM=wx4     Winograd F(4,3) along x on the f16 matrix pipe with split-fp16 position products (csrc/conv_f16_wx4.hip):
+#                            half of f16x3's MFMAs; layers / shapes it does not cover run as f16x3
+#   VIRNET_CONV_FORM=f16x3   split-fp16 operands on the f16 matrix pipe (csrc/conv_f16.hip)
 #   VIRNET_CONV_FORM=wino    Winograd F(2x2,3x3) on the fp32 matrix pipe (csrc/wino_row.hip)
 #   VIRNET_CONV_FORM=direct  fp32 implicit GEMM (csrc/conv_mfma.hip)
 #   VIRNET_CONV_FORM=bf16    REDUCED precision (BASELINE configs[4]'s training variant): the C->C stride-1 3x3 convs and their input-gradient
@@ -97,13 +101,40 @@ def conv_form() -> str:
     if form is None:
         legacy = os.environ.get("VIRNET_WINOGRAD")
         form = DEFAULT_CONV_FORM if legacy is None else ("direct" if legacy == "0" else "wino")
-    if form not in ("f16x3", "wino", "direct", "bf16"):
-        raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected f16x3, wino, direct or bf16")
+    if form not in ("f16x3", "wino", "direct", "bf16", "wx4"):
+        raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected wx4, f16x3, wino, direct or bf16")
     return form
 
 
 def _f16_family() -> bool:
-    return conv_form() in ("f16x3", "bf16")
+    return conv_form() in ("f16x3", "bf16", "wx4")
+
+
+def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
+    """The Winograd-along-x kernel works on 16 x 32 pixel tiles x 96 channels, one workgroup per CU: worth it when the image fills its
+    tiles reasonably and the launch gives the chip's 256 CUs work (VIRNET_WX4_MIN_WG overrides the workgroup floor; tests use 0)."""
+    th, tw = (h + 15) // 16, (w + 31) // 32
+    wgs = n * th * tw * ((cout + 95) // 96)
+    fill = (h * w) / float(th * 16 * tw * 32)
+    return wgs >= int(os.environ.get("VIRNET_WX4_MIN_WG", "192")) and fill >= float(os.environ.get("VIRNET_WX4_MIN_FILL", "0.6"))
+
+
+def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
+    """Winograd-along-x split-fp16 image (+ per-row inverse scales) of an OIHW 3x3 weight for virnet_conv_wx4."""
+    lib = nat.load()
+    weight = weight.detach()
+    _dev_check(weight, "weight")
+    cout, cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("the Winograd form is for 3x3 kernels")
+    rows, ks = (cin, cout) if dgrad else (cout, cin)
+    if rows % 32:
+        raise ValueError(f"virnet_conv_wx4 stores multiples of 32 channels, got {rows}")
+    cin_pad = (ks + 15) // 16 * 16
+    out = torch.empty(lib.virnet_wx4_weight_floats(cin_pad, rows), dtype=torch.float32, device=weight.device)
+    nat.check(lib.virnet_pack_wx4_weight(nat.ptr(weight), int(dgrad), cout, cin, cin_pad, rows, nat.ptr(out), nat.stream_handle()),
+              "pack_wx4_weight")
+    return out
 
 
 def _wino_enabled() -> bool:
@@ -194,6 +225,8 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
                 pw.f16 = pack_f16_weight(weight, dgrad=True)
                 if conv_form() == "bf16":
                     pw.bf16 = pack_f16_weight(weight, dgrad=True, bf16=True)
+                if conv_form() == "wx4":
+                    pw.wx4 = pack_wx4_weight(weight, dgrad=True)
         return pw
     if transposed:
         cin, cout, kh, kw = weight.shape
@@ -230,6 +263,8 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
             pw.f16 = pack_f16_weight(weight)
             if conv_form() == "bf16" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
                 pw.bf16 = pack_f16_weight(weight, bf16=True)
+            if conv_form() == "wx4" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
+                pw.wx4 = pack_wx4_weight(weight)
     return pw
 
 
@@ -277,9 +312,11 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
             form = "wino"
         elif want == "bf16" and pw.bf16 is not None:
             form = "bf16"
-        elif want in ("f16x3", "bf16") and pw.f16 is not None and pw.cout % 32 == 0:
+        elif want == "wx4" and pw.wx4 is not None and wx4_shape_ok(n, h, w, pw.cout):
+            form = "wx4"
+        elif want in ("f16x3", "bf16", "wx4") and pw.f16 is not None and pw.cout % 32 == 0:
             form = "f16x3"
-    wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16, "bf16": pw.bf16}[form]
+    wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16, "bf16": pw.bf16, "wx4": pw.wx4}[form]
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
@@ -287,7 +324,7 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
-    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16", "bf16": "conv_bf16"}[form], form)
+    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16", "bf16": "conv_bf16", "wx4": "conv_wx4"}[form], form)
     return raw, act
 
 
@@ -531,7 +568,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     else:
         cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
     form = conv_form()
-    if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16")
+    if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16", "wx4")
             and os.environ.get("VIRNET_WGRAD_FORM", "f16") != "f32"):
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
         return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),

@@ -36,7 +36,7 @@ class _Tape:
 
 
 def _thin(conv, x, crop, **kw):
-    if ops.conv_form() in ("f16x3", "bf16") and conv.cout <= 32:
+    if ops._f16_family() and conv.cout <= 32:
         return ops.conv_f16_nchw(x, conv.packed(), crop, **kw)
     return ops.conv3x3_thin(x, conv.packed_thin(), crop, **kw) if conv.cout <= 4 else ops.conv_mfma_nchw(x, conv.packed(), crop, **kw)
 
