@@ -56,12 +56,20 @@ __device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
 }
 
 struct WxItem {
-  unsigned off[6];   // element offsets of the six input pixels (clamped into the image), channel quad included
+  unsigned voff;     // byte offset of the item's first input pixel (row, 4*xtile - 1) from the image base; may wrap (the load is masked)
   unsigned inb;      // bit b: pixel b lies inside the image
-  int dst;           // byte offset of this (row, x-tile, quad) inside a V plane
+  int dst;           // byte offset of this item inside a V plane
 };
 
-template <int NREP, int EPI>
+// BT rows as coefficient vectors (the halo rows are staged one value per thread: v = sum_b c[b] * d[b])
+__device__ __forceinline__ float wx4_coef(int j, int b) {
+  constexpr float BT[6][6] = {{4.f, 0.f, -5.f, 0.f, 1.f, 0.f}, {0.f, -4.f, -4.f, 1.f, 1.f, 0.f}, {0.f, 4.f, -4.f, -1.f, 1.f, 0.f},
+                              {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, 4.f, 0.f, -5.f, 0.f, 1.f}};
+  return BT[j][b];
+}
+
+// PRE = 1: the conv consumes lrelu(x*in_mul+in_add, in_slope) (AttResUNet.py:54-55) applied while x is staged; PRE = 0: plain x.
+template <int NREP, int EPI, int PRE>
 __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   constexpr int NB = 32 * NREP;
   constexpr int NDMA = 12 * NREP;                  // 1-KB pieces of one weight stage: [jt][dy][slab][hi|lo]
@@ -91,55 +99,81 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const int l31 = lane & 31, lhi = lane >> 5;
   const int jt = wave & 1, rb = wave >> 1;
   const int nch = a.Cin >> 4;
-  const int nstages = nch * 3;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
+  // every pixel load goes through a buffer descriptor of this image: 32-bit offsets (vector: item + pixel, scalar: chunk), no 64-bit
+  // address arithmetic
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, a.H * a.W * a.Cin * 4, 0x00020000);
+  const int pxb = a.Cin * 4;                       // bytes per pixel
 
-  // ---- staging items: (V row, x-tile, channel quad); item 0 = rows 0..15 (every thread), item 1 = rows 16,17 (one wave per chunk)
-  const int sxt = (lane >> 2) & 7, sq = lane & 3;
-  auto make_item = [&](int srow) {
+  // ---- staging.  Main item of a thread: (V row 0..15, x-tile, channel quad): 6 pixels x 4 channels -> 6 positions x 4 channels.
+  // The tile's two halo rows (V rows 16, 17) are 2 x 8 x 16 x 6 values = 512 per position pair: ONE value per thread and stage.
+  auto item_at = [&](int srow, int sxt, int chan, int dst) {
     WxItem it;
-    const int gy = oy0 - 1 + srow;
+    const int gy = oy0 - 1 + srow, gx0 = ox0 - 1 + 4 * sxt;
     const bool rin = (unsigned)gy < (unsigned)a.H;
-    const int gyc = min(max(gy, 0), a.H - 1);
     it.inb = 0;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const int gx = ox0 - 1 + 4 * sxt + b;
-      const bool in = rin && (unsigned)gx < (unsigned)a.W;
-      const int gxc = min(max(gx, 0), a.W - 1);
-      it.off[b] = (unsigned)((gyc * a.W + gxc) * a.Cin + 4 * sq);
-      it.inb |= (in ? 1u : 0u) << b;
-    }
-    it.dst = (srow * 8 + sxt) * 32 + ((((sq >> 1) ^ (srow & 1))) << 4) + (sq & 1) * 8;
+    for (int b = 0; b < 6; ++b) it.inb |= ((rin && (unsigned)(gx0 + b) < (unsigned)a.W) ? 1u : 0u) << b;
+    it.voff = (unsigned)(((gy * a.W + gx0) * a.Cin + chan) * 4);
+    it.dst = dst;
     return it;
   };
-  const WxItem it0 = make_item(tid >> 5);
-  const WxItem it1 = make_item(16 + (lane >> 5));
-  const bool in_sft = a.in_mul != nullptr;
-  const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + 4 * sq : nullptr;
-  const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + 4 * sq : nullptr;
+  const int sxt = (lane >> 2) & 7, sq = lane & 3, srow = tid >> 5;
+  const WxItem it0 = item_at(srow, sxt, 4 * sq, (srow * 8 + sxt) * 32 + ((((sq >> 1) ^ (srow & 1))) << 4) + (sq & 1) * 8);
+  // halo value of this thread: position jw + 3*hp of the pair being written, row 16 + (hg>>1), x-tile (hg&1)*4 + (lane>>4), channel lane&15
+  const int hp = wave & 1, hg = wave >> 1, hch = lane & 15;
+  const int hrow = 16 + (hg >> 1), hxt = (hg & 1) * 4 + (lane >> 4);
+  const WxItem ith = item_at(hrow, hxt, hch, (hrow * 8 + hxt) * 32 + ((((hch >> 3) ^ (hrow & 1))) << 4) + (hch & 7) * 2);
+  float hc[3][6];                                  // (wave-uniform) coefficients of the halo value per stage-pair
+#pragma unroll
+  for (int jw = 0; jw < 3; ++jw)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) hc[jw][b] = hp ? wx4_coef(jw + 3, b) : wx4_coef(jw, b);
+  char* const vh_lds = v_lds + hp * 3 * WX_POS;
+
+  const bool in_sft = PRE && a.in_mul != nullptr;
+  // (no SFT: read something valid and ignore it -- the staging code has no branch)
+  const float* const imul = (in_sft ? a.in_mul : a.inv_scale) + (in_sft ? (size_t)img * a.Cin : 0);
+  const float* const iadd = (in_sft ? a.in_add : a.inv_scale) + (in_sft ? (size_t)img * a.Cin : 0);
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
-  auto load_raw = [&](f32x4 (&d)[6], const WxItem& it, int chunk) {
+  auto load_raw = [&](f32x4 (&d)[6], float (&dh)[6], int chunk) {
+    // (a pixel outside the image is read at offset 0 and masked afterwards: the descriptor's range check sees the vector offset alone,
+    // so an item whose FIRST pixel lies left of / above the image cannot carry its offset in wrapped form)
+    const int so = chunk * 64;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const f32x4*>(ximg + it.off[b] + chunk * 16);
+    for (int b = 0; b < 6; ++b)
+      d[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : 0u, so, 0));
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : 0u, so, 0));
   };
-  // pre-activation (AttResUNet.py:54-55: lrelu(x*mul+add)), zero outside the image AFTER it
-  auto preact = [&](f32x4 (&d)[6], const WxItem& it, int chunk) {
-    f32x4 m = f32x4{1.f, 1.f, 1.f, 1.f}, ad = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (in_sft) {
-      m = *reinterpret_cast<const f32x4*>(imul + chunk * 16);
-      ad = *reinterpret_cast<const f32x4*>(iadd + chunk * 16);
-    }
+  // pre-activation, then zero outside the image ("pad after activation")
+  auto preact = [&](f32x4 (&d)[6], float (&dh)[6], int chunk) {
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PRE) {
+      f32x4 m = *reinterpret_cast<const f32x4*>(imul + (in_sft ? chunk * 16 + 4 * sq : 0));
+      f32x4 ad = *reinterpret_cast<const f32x4*>(iadd + (in_sft ? chunk * 16 + 4 * sq : 0));
+      float mh = imul[in_sft ? chunk * 16 + hch : 0], ah = iadd[in_sft ? chunk * 16 + hch : 0];
+      m = in_sft ? m : f32x4{1.f, 1.f, 1.f, 1.f};
+      ad = in_sft ? ad : z;
+      mh = in_sft ? mh : 1.f;
+      ah = in_sft ? ah : 0.f;
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      f32x4 v = d[b];
-      if (in_sft) v = v * m + ad;
-      v = lrelu4(v, in_slope_eff);
-      d[b] = ((it.inb >> b) & 1u) ? v : z;
+      for (int b = 0; b < 6; ++b) {
+        const f32x4 v = lrelu4(d[b] * m + ad, in_slope_eff);
+        d[b] = ((it0.inb >> b) & 1u) ? v : z;
+        const float u = dh[b] * mh + ah;
+        dh[b] = ((ith.inb >> b) & 1u) ? fmaxf(u, u * in_slope_eff) : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        d[b] = ((it0.inb >> b) & 1u) ? d[b] : z;
+        dh[b] = ((ith.inb >> b) & 1u) ? dh[b] : 0.f;
+      }
     }
   };
-  auto put = [&](auto jc, const f32x4 (&d)[6], const WxItem& it) {
+  auto put = [&](auto jc, const f32x4 (&d)[6]) {
     constexpr int J = decltype(jc)::value;
     const f32x4 v = wx4_pos<J>(d);
     h4 hi, lo;
@@ -148,8 +182,19 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       hi[e] = (_Float16)v[e];
       lo[e] = (_Float16)(v[e] - (float)hi[e]);
     }
-    *reinterpret_cast<h4*>(v_lds + J * WX_POS + it.dst) = hi;
-    *reinterpret_cast<h4*>(v_lds + J * WX_POS + WX_PLANE + it.dst) = lo;
+    *reinterpret_cast<h4*>(v_lds + J * WX_POS + it0.dst) = hi;
+    *reinterpret_cast<h4*>(v_lds + J * WX_POS + WX_PLANE + it0.dst) = lo;
+  };
+  auto put_halo = [&](auto jwc, const float (&dh)[6]) {
+    constexpr int JW = decltype(jwc)::value;
+    float v = 0.f;
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+      if (wx4_coef(JW, b) != 0.f || wx4_coef(JW + 3, b) != 0.f) v = fmaf(hc[JW][b], dh[b], v);
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + ith.dst) = hi;
+    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + WX_PLANE + ith.dst) = lo;
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -158,27 +203,25 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   using I4 = std::integral_constant<int, 4>;
   using I5 = std::integral_constant<int, 5>;
 
-  // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB]
+  // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB].
+  // Waves without a piece in the last round move their previous piece again (same bytes to the same place): no branch.
   const size_t slab_bytes = (size_t)nch * WX_CHUNK_BYTES;
   const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes + lane * 16;
-  int poff[NDI];
+  int poff[NDI], pdst[NDI];
 #pragma unroll
   for (int i = 0; i < NDI; ++i) {
-    const int qd = min(i * 8 + wave, NDMA - 1);
+    int qd = i * 8 + wave;
+    if (qd >= NDMA) qd -= 8;
     const int jq = qd / (6 * NREP), r = qd - jq * (6 * NREP);
     const int dq = r / (2 * NREP), r2 = r - dq * (2 * NREP);
     poff[i] = __builtin_amdgcn_readfirstlane((r2 >> 1) * (int)slab_bytes + jq * (3 * 3 * 2048) + dq * 2048 + (r2 & 1) * 1024);
+    pdst[i] = __builtin_amdgcn_readfirstlane(qd * 1024);
   }
   auto dma_stage = [&](int src_off, char* wb) {            // src_off = chunk * 36 KB + ji * 6 KB
 #pragma unroll
-    for (int i = 0; i < NDI; ++i) {
-      const int qd = i * 8 + wave;
-      if (qd < NDMA) {
-        const char* src = wcb + src_off + poff[i];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(wb + qd * 1024), 16, 0, 0);
-      }
-    }
+    for (int i = 0; i < NDI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wcb + src_off + poff[i]),
+                                       (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, 0, 0);
   };
 
   // ---- fragment addressing
@@ -201,52 +244,53 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 
   // ---- prologue: weights of stage 0 by DMA; chunk 0's pixels -> positions {0,3} and {1,4} ({2,5} are written by stage 0 itself)
   dma_stage(0, w_lds);
-  f32x4 d0[6], d1[6];
-  load_raw(d0, it0, 0);
-  if (wave == 0) load_raw(d1, it1, 0);
-  preact(d0, it0, 0);
-  put(I0{}, d0, it0); put(I3{}, d0, it0); put(I1{}, d0, it0); put(I4{}, d0, it0);
-  if (wave == 0) {
-    preact(d1, it1, 0);
-    put(I0{}, d1, it1); put(I3{}, d1, it1); put(I1{}, d1, it1); put(I4{}, d1, it1);
-  }
+  f32x4 d0[6];
+  float dh[6];
+  load_raw(d0, dh, 0);
+  preact(d0, dh, 0);
+  put(I0{}, d0); put(I3{}, d0); put(I1{}, d0); put(I4{}, d0);
+  put_halo(I0{}, dh); put_halo(I1{}, dh);
   __syncthreads();
   TSTAMP(1);
 
-  // One stage = positions {ji, 3+ji} of chunk c.  d0 / d1 hold the (pre-activated from stage 1 on) pixels of chunk `cd`: the chunk
-  // whose V planes are being written -- c itself in stage 0, c+1 in stages 1 and 2 (the last chunk rewrites its own dead planes).
+  // One stage = positions {ji, 3+ji} of chunk c.  d0 / dh hold the pixels of the chunk whose V planes are being written: c itself in
+  // stage 0 (planes {2,5}), c+1 in stages 1 and 2 (planes {0,3}, {1,4}; the last chunk rewrites its own dead planes).
   auto stage = [&](int c, auto jic) {
     constexpr int ji = decltype(jic)::value;
     const int s = c * 3 + ji;
     const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
     char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
-    if (s + 1 < nstages) dma_stage(ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : (c + 1) * WX_CHUNK_BYTES, wn);
     const int cn = min(c + 1, nch - 1);
+    // next stage's weights (the last stage fetches itself again into the idle buffer)
+    dma_stage(ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : cn * WX_CHUNK_BYTES + (c + 1 < nch ? 0 : 2 * 6144), wn);
     if constexpr (ji == 0) {
-      put(I2{}, d0, it0); put(I5{}, d0, it0);
-      if (wave == (c & 7)) { put(I2{}, d1, it1); put(I5{}, d1, it1); }
-      load_raw(d0, it0, cn);
-      if (wave == (cn & 7)) load_raw(d1, it1, cn);
+      put(I2{}, d0); put(I5{}, d0);
+      put_halo(I2{}, dh);
+      load_raw(d0, dh, cn);
     } else if constexpr (ji == 1) {
-      preact(d0, it0, cn);
-      put(I0{}, d0, it0); put(I3{}, d0, it0);
-      if (wave == (cn & 7)) { preact(d1, it1, cn); put(I0{}, d1, it1); put(I3{}, d1, it1); }
+      preact(d0, dh, cn);
+      put(I0{}, d0); put(I3{}, d0);
+      put_halo(I0{}, dh);
     } else {
-      put(I1{}, d0, it0); put(I4{}, d0, it0);
-      if (wave == (cn & 7)) { put(I1{}, d1, it1); put(I4{}, d1, it1); }
+      put(I1{}, d0); put(I4{}, d0);
+      put_halo(I1{}, dh);
     }
     const char* const vb = vjt + ji * WX_POS;
+    h8 bh[3], bl[3];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const h8 bh = *reinterpret_cast<const h8*>(vb + boff[dy]);
-      const h8 bl = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
+      bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
+      bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
 #pragma unroll
       for (int nr = 0; nr < NREP; ++nr) {
         const h8 ah = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 0) * 1024);
         const h8 al = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 1) * 1024);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[dy], acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[dy], acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[dy], acc[ji][nr], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -410,14 +454,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   TSTAMP(3);
 }
 
-template <int NREP, int EPI>
+template <int NREP, int EPI, int PRE>
 int launch_wx4(FArgs k, hipStream_t st) {
   constexpr int LDS_K = WX_VBYTES + 2 * 12 * NREP * 1024;
   constexpr int LDS_E = 24 * WX_XBLK;
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static_assert(LDS <= 160 * 1024, "one workgroup per CU");
   static unsigned long long attr_done = 0;
-  auto kern = conv_wx4_kernel<NREP, EPI>;
+  auto kern = conv_wx4_kernel<NREP, EPI, PRE>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wx4): %s", hipGetErrorString(e));
@@ -529,6 +573,7 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nb = d->n_pad / 32;
   const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
+  const bool pre = d->in_act != 0;
   // slabs per workgroup: 3 where the count allows, the remainder in 2s (160 = 3 + 2, 224 = 3 + 2 + 2), a lone odd slab by itself
   int n3 = nb / 3, rem = nb - 3 * n3;
   if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
@@ -538,13 +583,13 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
-#define VIRNET_WX4_CASE(N_)                                      \
-    if (nrep == N_) {                                            \
-      if (epi == 0) return launch_wx4<N_, 0>(kk, st);            \
-      if (epi == 1) return launch_wx4<N_, 1>(kk, st);            \
-      if (epi == 2) return launch_wx4<N_, 2>(kk, st);            \
-      if (epi == 3) return launch_wx4<N_, 3>(kk, st);            \
-      return launch_wx4<N_, 4>(kk, st);                          \
+#define VIRNET_WX4_CASE(N_)                                                                              \
+    if (nrep == N_) {                                                                                    \
+      if (epi == 0) return pre ? launch_wx4<N_, 0, 1>(kk, st) : launch_wx4<N_, 0, 0>(kk, st);            \
+      if (epi == 1) return pre ? launch_wx4<N_, 1, 1>(kk, st) : launch_wx4<N_, 1, 0>(kk, st);            \
+      if (epi == 2) return pre ? launch_wx4<N_, 2, 1>(kk, st) : launch_wx4<N_, 2, 0>(kk, st);            \
+      if (epi == 3) return pre ? launch_wx4<N_, 3, 1>(kk, st) : launch_wx4<N_, 3, 0>(kk, st);            \
+      return pre ? launch_wx4<N_, 4, 1>(kk, st) : launch_wx4<N_, 4, 0>(kk, st);                          \
     }
     VIRNET_WX4_CASE(3) VIRNET_WX4_CASE(2) VIRNET_WX4_CASE(1)
 #undef VIRNET_WX4_CASE
