@@ -9,7 +9,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmcf/c -o p --output-
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmcf/d -o p --output-format csv -- python $R/tools/bench_conv.py --shapes $SH --mode $MODE --iters 5 > /dev/null 2>&1
 python - <<PY
 import csv,glob,collections
-K="conv_f16_kernel"
+K="${KERNEL:-conv_f16_kernel}"
 out={}
 for sub in "abcd":
     d="$R/gpurun_out/pmcf/"+sub

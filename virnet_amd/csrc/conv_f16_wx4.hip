@@ -42,7 +42,13 @@ constexpr int WX_PLANE = 18 * 8 * 32;        // one (position, hi|lo) plane: [18
 constexpr int WX_POS = 2 * WX_PLANE;
 constexpr int WX_VBYTES = 6 * WX_POS;        // 55296
 constexpr int WX_XBLK = 32 * 144 + 64;       // exchange block: [32 columns][32 channels + 16 B pad], skewed by 64 B against its neighbours
-constexpr int WX_CHUNK_BYTES = 36 * 1024;    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
+constexpr int WX_CHUNK_BYTES = 36 * 1024;
+#ifndef WX_HEAD_VALU
+#define WX_HEAD_VALU 24      // staging VALU ops issued behind the first fragment reads of a stage (they cover the LDS latency)
+#endif
+#ifndef WX_GAP_VALU
+#define WX_GAP_VALU 3        // ... and behind every MFMA
+#endif    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
 
 template <int J>
 __device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
@@ -68,7 +74,8 @@ __device__ __forceinline__ float wx4_coef(int j, int b) {
   return BT[j][b];
 }
 
-// PRE = 1: the conv consumes lrelu(x*in_mul+in_add, in_slope) (AttResUNet.py:54-55) applied while x is staged; PRE = 0: plain x.
+// PRE: what the conv applies to x while it is staged -- 0: nothing; 1: lrelu(x, in_slope); 2: lrelu(x*in_mul+in_add, in_slope), the SFT
+// pre-activation of AttResUNet.py:54-55 with per-(image, channel) vectors.
 template <int NREP, int EPI, int PRE>
 __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   constexpr int NB = 32 * NREP;
@@ -131,11 +138,11 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     for (int b = 0; b < 6; ++b) hc[jw][b] = hp ? wx4_coef(jw + 3, b) : wx4_coef(jw, b);
   char* const vh_lds = v_lds + hp * 3 * WX_POS;
 
-  const bool in_sft = PRE && a.in_mul != nullptr;
-  // (no SFT: read something valid and ignore it -- the staging code has no branch)
-  const float* const imul = (in_sft ? a.in_mul : a.inv_scale) + (in_sft ? (size_t)img * a.Cin : 0);
-  const float* const iadd = (in_sft ? a.in_add : a.inv_scale) + (in_sft ? (size_t)img * a.Cin : 0);
-  const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  const float* const imul = PRE == 2 ? a.in_mul + (size_t)img * a.Cin : nullptr;
+  const float* const iadd = PRE == 2 ? a.in_add + (size_t)img * a.Cin : nullptr;
+  const float in_slope_eff = a.in_slope;
+  f32x4 sm = f32x4{1.f, 1.f, 1.f, 1.f}, sa = f32x4{0.f, 0.f, 0.f, 0.f};     // SFT vectors of the chunk in d0 / dh (PRE == 2)
+  float smh = 1.f, sah = 0.f;
   auto load_raw = [&](f32x4 (&d)[6], float (&dh)[6], int chunk) {
     // (a pixel outside the image is read at offset 0 and masked afterwards: the descriptor's range check sees the vector offset alone,
     // so an item whose FIRST pixel lies left of / above the image cannot carry its offset in wrapped form)
@@ -146,31 +153,29 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
     for (int b = 0; b < 6; ++b)
       dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : 0u, so, 0));
+    if constexpr (PRE == 2) {
+      sm = *reinterpret_cast<const f32x4*>(imul + chunk * 16 + 4 * sq);
+      sa = *reinterpret_cast<const f32x4*>(iadd + chunk * 16 + 4 * sq);
+      smh = imul[chunk * 16 + hch];
+      sah = iadd[chunk * 16 + hch];
+    }
   };
   // pre-activation, then zero outside the image ("pad after activation")
-  auto preact = [&](f32x4 (&d)[6], float (&dh)[6], int chunk) {
+  auto preact = [&](f32x4 (&d)[6], float (&dh)[6]) {
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PRE) {
-      f32x4 m = *reinterpret_cast<const f32x4*>(imul + (in_sft ? chunk * 16 + 4 * sq : 0));
-      f32x4 ad = *reinterpret_cast<const f32x4*>(iadd + (in_sft ? chunk * 16 + 4 * sq : 0));
-      float mh = imul[in_sft ? chunk * 16 + hch : 0], ah = iadd[in_sft ? chunk * 16 + hch : 0];
-      m = in_sft ? m : f32x4{1.f, 1.f, 1.f, 1.f};
-      ad = in_sft ? ad : z;
-      mh = in_sft ? mh : 1.f;
-      ah = in_sft ? ah : 0.f;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const f32x4 v = lrelu4(d[b] * m + ad, in_slope_eff);
-        d[b] = ((it0.inb >> b) & 1u) ? v : z;
-        const float u = dh[b] * mh + ah;
-        dh[b] = ((ith.inb >> b) & 1u) ? fmaxf(u, u * in_slope_eff) : 0.f;
+    for (int b = 0; b < 6; ++b) {
+      f32x4 v = d[b];
+      float u = dh[b];
+      if constexpr (PRE == 2) { v = v * sm + sa; u = u * smh + sah; }
+      if constexpr (PRE >= 1) {        // max(v, slope*v) as a median with +inf: no canonicalising copy of the loaded value
+        const float inf = __builtin_inff();
+        v = f32x4{__builtin_amdgcn_fmed3f(v.x, v.x * in_slope_eff, inf), __builtin_amdgcn_fmed3f(v.y, v.y * in_slope_eff, inf),
+                  __builtin_amdgcn_fmed3f(v.z, v.z * in_slope_eff, inf), __builtin_amdgcn_fmed3f(v.w, v.w * in_slope_eff, inf)};
+        u = __builtin_amdgcn_fmed3f(u, u * in_slope_eff, inf);
       }
-    } else {
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        d[b] = ((it0.inb >> b) & 1u) ? d[b] : z;
-        dh[b] = ((ith.inb >> b) & 1u) ? dh[b] : 0.f;
-      }
+      d[b] = ((it0.inb >> b) & 1u) ? v : z;
+      dh[b] = ((ith.inb >> b) & 1u) ? u : 0.f;
     }
   };
   auto put = [&](auto jc, const f32x4 (&d)[6]) {
@@ -247,20 +252,37 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   f32x4 d0[6];
   float dh[6];
   load_raw(d0, dh, 0);
-  preact(d0, dh, 0);
+  preact(d0, dh);
   put(I0{}, d0); put(I3{}, d0); put(I1{}, d0); put(I4{}, d0);
   put_halo(I0{}, dh); put_halo(I1{}, dh);
   __syncthreads();
   TSTAMP(1);
 
-  // One stage = positions {ji, 3+ji} of chunk c.  d0 / dh hold the pixels of the chunk whose V planes are being written: c itself in
-  // stage 0 (planes {2,5}), c+1 in stages 1 and 2 (planes {0,3}, {1,4}; the last chunk rewrites its own dead planes).
+  // One stage = positions {ji, 3+ji} of chunk c: NG = 3*NREP groups (dy, slab) of three MFMAs.  d0 / dh hold the pixels of the chunk
+  // whose V planes are being written: c itself in stage 0 (planes {2,5}), c+1 in stages 1 and 2 (planes {0,3}, {1,4}; the last chunk
+  // rewrites its own dead planes).  The body is ONE basic block: fragments are read one group ahead into distinct registers and the
+  // staging arithmetic / LDS writes / loads are threaded between the MFMAs by sched_group_barrier (a wave issues in order and an MFMA
+  // holds the pipe for 32 cycles).
   auto stage = [&](int c, auto jic) {
     constexpr int ji = decltype(jic)::value;
+    constexpr int NG = 3 * NREP;
     const int s = c * 3 + ji;
     const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
     char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
     const int cn = min(c + 1, nch - 1);
+    const char* const vb = vjt + ji * WX_POS;
+    h8 ah[NG], al[NG], bh[3], bl[3];
+    auto rd_a = [&](int g) {
+      ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
+      al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
+    };
+    auto rd_b = [&](int dy) {
+      bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
+      bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
+    };
+    SB();
+    rd_a(0);
+    rd_b(0);
     // next stage's weights (the last stage fetches itself again into the idle buffer)
     dma_stage(ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : cn * WX_CHUNK_BYTES + (c + 1 < nch ? 0 : 2 * 6144), wn);
     if constexpr (ji == 0) {
@@ -268,31 +290,46 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       put_halo(I2{}, dh);
       load_raw(d0, dh, cn);
     } else if constexpr (ji == 1) {
-      preact(d0, dh, cn);
+      preact(d0, dh);
       put(I0{}, d0); put(I3{}, d0);
       put_halo(I0{}, dh);
     } else {
       put(I1{}, d0); put(I4{}, d0);
       put_halo(I1{}, dh);
     }
-    const char* const vb = vjt + ji * WX_POS;
-    h8 bh[3], bl[3];
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
-      bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
-    }
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-      for (int nr = 0; nr < NREP; ++nr) {
-        const h8 ah = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 0) * 1024);
-        const h8 al = *reinterpret_cast<const h8*>(wb + ((dy * NREP + nr) * 2 + 1) * 1024);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[dy], acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[dy], acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[dy], acc[ji][nr], 0, 0, 0);
+    for (int g = 0; g < NG; ++g) {
+      const int dy = g / NREP, nr = g - dy * NREP;
+      if (g + 1 < NG) {
+        rd_a(g + 1);
+        if ((g + 1) % NREP == 0) rd_b((g + 1) / NREP);
       }
+      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[dy], acc[ji][nr], 0, 0, 0);
+      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[dy], acc[ji][nr], 0, 0, 0);
+      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[dy], acc[ji][nr], 0, 0, 0);
     }
+    // ---- the order of issue
+    constexpr int NVM = ji == 0 ? 12 + (PRE == 2 ? 4 : 0) : 0;        // pixel (+ SFT vector) loads of stage 0
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, NDI, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, WX_HEAD_VALU, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const bool rd = g + 1 < NG, rdb = rd && (g + 1) % NREP == 0;
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
+      if (g * 2 < NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
+      if (g * 2 + 1 < NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (rdb) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    SB();
     __syncthreads();
   };
   for (int c = 0; c < nch; ++c) {
@@ -366,29 +403,23 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     const float slope_eff = a.y_act ? a.slope : 1.f;
     const float* const bp = a.bias ? a.bias : a.inv_scale;
     const float hb = a.bias ? 1.f : 0.f;
-    constexpr bool HOIST = EPI == 1 || EPI == 2;
-    f32x4 bias4[NREP], inv4[NREP], op1[HOIST ? NREP : 1][NIT];
+    // The operand tile of slab nr+1 (residual or mask) is requested at the start of slab nr's read phase, BEFORE that slab's stores: a
+    // load consumed behind pending stores waits for their acknowledgement (one in-order counter for both), and by the time slab nr+1
+    // is consumed the only stores ahead of its loads are those of slab nr-1, a whole phase old.  Two operand tiles live at most.
+    constexpr bool ONE = EPI == 1 || EPI == 2;
+    f32x4 bias4[NREP], inv4[NREP], op1[2][NIT];
     const float* const op1p = RES ? rimg : mimg;
+    auto load_op1 = [&](int nr) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) op1[nr & 1][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
+    };
     xwrite(0);
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nbase + nr * 32 + cq * 4);
       bias4[nr] = *reinterpret_cast<const f32x4*>(bp + nbase + nr * 32 + cq * 4);
-      if (HOIST) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) op1[nr][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
-      }
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int nr = 0; nr < NREP; ++nr) {
-      asm volatile("" ::"v"(inv4[nr]), "v"(bias4[nr]));
-      if (HOIST) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) asm volatile("" ::"v"(op1[nr][it]));
-      }
-    }
-#endif
+    if (ONE) load_op1(0);
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
     unsigned yoff[NIT];
 #pragma unroll
@@ -397,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     for (int nr = 0; nr < NREP; ++nr) {
       if (nr > 0) xwrite(nr);
       __syncthreads();
+      if (ONE && nr + 1 < NREP) load_op1(nr + 1);
       f32x4 mv[NIT], rv[NIT];
       if (EPI == 3) {
 #pragma unroll
@@ -409,11 +441,17 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       f32x4 tv[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) tv[it] = xread(it);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (ONE && nr + 1 < NREP) {                    // keep the next slab's requests above this slab's stores
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(op1[(nr + 1) & 1][it]));
+      }
+#endif
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         f32x4 v = tv[it] * inv4[nr] + b4;
-        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[HOIST ? nr : 0][it]);
-        if (RES) v += EPI == 3 ? rv[it] : op1[HOIST ? nr : 0][it];
+        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[nr & 1][it]);
+        if (RES) v += EPI == 3 ? rv[it] : op1[nr & 1][it];
         v = lrelu4(v, slope_eff);
         // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
@@ -573,7 +611,7 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nb = d->n_pad / 32;
   const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
-  const bool pre = d->in_act != 0;
+  const int pre = d->in_mul ? 2 : (d->in_act != 0);
   // slabs per workgroup: 3 where the count allows, the remainder in 2s (160 = 3 + 2, 224 = 3 + 2 + 2), a lone odd slab by itself
   int n3 = nb / 3, rem = nb - 3 * n3;
   if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
@@ -583,16 +621,15 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
+#define VIRNET_WX4_EPI(N_, E_)                                                                                               \
+    if (epi == E_) return pre == 2 ? launch_wx4<N_, E_, 2>(kk, st) : pre == 1 ? launch_wx4<N_, E_, 1>(kk, st) : launch_wx4<N_, E_, 0>(kk, st);
 #define VIRNET_WX4_CASE(N_)                                                                              \
     if (nrep == N_) {                                                                                    \
-      if (epi == 0) return pre ? launch_wx4<N_, 0, 1>(kk, st) : launch_wx4<N_, 0, 0>(kk, st);            \
-      if (epi == 1) return pre ? launch_wx4<N_, 1, 1>(kk, st) : launch_wx4<N_, 1, 0>(kk, st);            \
-      if (epi == 2) return pre ? launch_wx4<N_, 2, 1>(kk, st) : launch_wx4<N_, 2, 0>(kk, st);            \
-      if (epi == 3) return pre ? launch_wx4<N_, 3, 1>(kk, st) : launch_wx4<N_, 3, 0>(kk, st);            \
-      return pre ? launch_wx4<N_, 4, 1>(kk, st) : launch_wx4<N_, 4, 0>(kk, st);                          \
+      VIRNET_WX4_EPI(N_, 0) VIRNET_WX4_EPI(N_, 1) VIRNET_WX4_EPI(N_, 2) VIRNET_WX4_EPI(N_, 3) VIRNET_WX4_EPI(N_, 4)                          \
     }
     VIRNET_WX4_CASE(3) VIRNET_WX4_CASE(2) VIRNET_WX4_CASE(1)
 #undef VIRNET_WX4_CASE
+#undef VIRNET_WX4_EPI
     return virnet::set_error("virnet_conv_wx4: no kernel for nrep=%d", nrep);
   };
   if (int rc = run(3, 0, n3)) return rc;
