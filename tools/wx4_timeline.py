@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Where a workgroup of conv_wx4_kernel spends its time (a -DVIRNET_F16_TIMING build: tools/build_variant.sh timing -DVIRNET_F16_TIMING):
+    VIRNET_HIP_LIB=$PWD/virnet_amd/lib/libvirnet_hip_timing.so python tools/wx4_timeline.py [--shape l0] [--mode pre]
+Wave 0 stamps s_memtime at start / after the prologue / after the K loop / at exit; waves 0 and 1 also sum, per stage type ji = 0,1,2,
+the cycles until they reach the end-of-stage waits, the cycles in `s_waitcnt vmcnt(0)` and the cycles in the barrier."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["VIRNET_CONV_FORM"] = "wx4"
+from virnet_amd import _native as nat, ops  # noqa: E402
+from virnet_amd.networks.params import ConvParam  # noqa: E402
+from bench_conv import SHAPES  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="l0")
+    ap.add_argument("--mode", default="pre")
+    args = ap.parse_args()
+    n, h, w, c = SHAPES[args.shape]
+    lib = nat.load()
+    lib.virnet_debug_timing_buffer.argtypes = [C.c_void_p]
+    cp = ConvParam(c, c, 3).cuda()
+    x = torch.rand(n, h, w, c, device="cuda") - 0.5
+    res = torch.rand(n, h, w, c, device="cuda") - 0.5
+    kw = {"res": dict(res=res, want_raw=True), "pre": dict(in_slope=0.2, want_raw=False, want_act=True)}[args.mode]
+    pw = cp.packed()
+    ntiles = n * ((h + 15) // 16) * ((w + 31) // 32)
+    ncb = (c + 95) // 96
+    nwg = ntiles * ncb
+    log = torch.zeros(nwg * 16 + (nwg + 64) * 8 * 16 + 4096, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        ops.conv_mfma(x, pw, **kw)
+    torch.cuda.synchronize()
+    lib.virnet_debug_timing_buffer(log.data_ptr())
+    ops.conv_mfma(x, pw, **kw)
+    torch.cuda.synchronize()
+    lib.virnet_debug_timing_buffer(None)
+    t = log.cpu().numpy()
+    st = t[:nwg * 8 + 64].reshape(-1, 8)
+    st = st[st[:, 0] != 0]
+    pro, kl, ep = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
+    nst = (c // 16)
+    print(f"{len(st)} workgroups; per workgroup (median cycles): prologue {np.median(pro):.0f}, K loop {np.median(kl):.0f} "
+          f"({np.median(kl) / (3 * nst):.0f} per stage), epilogue {np.median(ep):.0f}")
+    acc = t[nwg * 16:nwg * 16 + nwg * 8 * 16].reshape(-1, 8, 16).astype(np.float64) / nst
+    acc = acc[acc[:, 0, 0] != 0]
+    for wv in range(8):
+        line = []
+        for ji in range(3):
+            wk, vm, lg, br = (np.median(acc[:, wv, ji * 4 + k]) for k in range(4))
+            line.append(f"ji={ji}: work {wk:5.0f} vm {vm:4.0f} lgkm {lg:4.0f} bar {br:5.0f}")
+        print(f"  wave {wv}: " + "  |  ".join(line))
+
+
+if __name__ == "__main__":
+    main()

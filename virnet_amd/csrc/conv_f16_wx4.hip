@@ -47,7 +47,7 @@ constexpr int WX_CHUNK_BYTES = 36 * 1024;
 #define WX_HEAD_VALU 24      // staging VALU ops issued behind the first fragment reads of a stage (they cover the LDS latency)
 #endif
 #ifndef WX_GAP_VALU
-#define WX_GAP_VALU 3        // ... and behind every MFMA
+#define WX_GAP_VALU 10       // ... and behind every group of three MFMAs
 #endif    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
 
 template <int J>
@@ -59,6 +59,14 @@ __device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
   if constexpr (J == 3) return (d[4] - d[2]) + 2.f * (d[3] - d[1]);
   if constexpr (J == 4) return (d[4] - d[2]) - 2.f * (d[3] - d[1]);
   return 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+// max of two floats as the bare instruction: fmaxf() on a value that comes straight from a load first copies it through a
+// canonicalising v_max x, x (IEEE sNaN quieting), one VALU op per staged value
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 struct WxItem {
@@ -143,16 +151,16 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const float in_slope_eff = a.in_slope;
   f32x4 sm = f32x4{1.f, 1.f, 1.f, 1.f}, sa = f32x4{0.f, 0.f, 0.f, 0.f};     // SFT vectors of the chunk in d0 / dh (PRE == 2)
   float smh = 1.f, sah = 0.f;
-  auto load_raw = [&](f32x4 (&d)[6], float (&dh)[6], int chunk) {
-    // (a pixel outside the image is read at offset 0 and masked afterwards: the descriptor's range check sees the vector offset alone,
-    // so an item whose FIRST pixel lies left of / above the image cannot carry its offset in wrapped form)
-    const int so = chunk * 64;
+  // pixel b of the main item / of the halo value.  (A pixel outside the image is read at offset 0 and masked afterwards: the
+  // descriptor's range check sees the vector offset alone, so an item whose FIRST pixel lies left of / above the image cannot carry
+  // its offset in wrapped form.)
+  auto load_px = [&](f32x4 (&d)[6], int b, int chunk) {
+    d[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : 0u, chunk * 64, 0));
+  };
+  auto load_halo = [&](float (&dh)[6], int chunk) {
 #pragma unroll
     for (int b = 0; b < 6; ++b)
-      d[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : 0u, so, 0));
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-      dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : 0u, so, 0));
+      dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : 0u, chunk * 64, 0));
     if constexpr (PRE == 2) {
       sm = *reinterpret_cast<const f32x4*>(imul + chunk * 16 + 4 * sq);
       sa = *reinterpret_cast<const f32x4*>(iadd + chunk * 16 + 4 * sq);
@@ -161,25 +169,35 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     }
   };
   // pre-activation, then zero outside the image ("pad after activation")
-  auto preact = [&](f32x4 (&d)[6], float (&dh)[6]) {
-    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto preact_px = [&](f32x4 (&d)[6], int b) {
+    f32x4 v = d[b];
+    if constexpr (PRE == 2) v = v * sm + sa;
+    if constexpr (PRE >= 1) v = f32x4{vmax(v.x, v.x * in_slope_eff), vmax(v.y, v.y * in_slope_eff), vmax(v.z, v.z * in_slope_eff), vmax(v.w, v.w * in_slope_eff)};
+    d[b] = ((it0.inb >> b) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto preact_halo = [&](float (&dh)[6]) {
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-      f32x4 v = d[b];
       float u = dh[b];
-      if constexpr (PRE == 2) { v = v * sm + sa; u = u * smh + sah; }
-      if constexpr (PRE >= 1) {        // max(v, slope*v) as a median with +inf: no canonicalising copy of the loaded value
-        const float inf = __builtin_inff();
-        v = f32x4{__builtin_amdgcn_fmed3f(v.x, v.x * in_slope_eff, inf), __builtin_amdgcn_fmed3f(v.y, v.y * in_slope_eff, inf),
-                  __builtin_amdgcn_fmed3f(v.z, v.z * in_slope_eff, inf), __builtin_amdgcn_fmed3f(v.w, v.w * in_slope_eff, inf)};
-        u = __builtin_amdgcn_fmed3f(u, u * in_slope_eff, inf);
-      }
-      d[b] = ((it0.inb >> b) & 1u) ? v : z;
+      if constexpr (PRE == 2) u = u * smh + sah;
+      if constexpr (PRE >= 1) u = vmax(u, u * in_slope_eff);
       dh[b] = ((ith.inb >> b) & 1u) ? u : 0.f;
     }
   };
   auto put = [&](auto jc, const f32x4 (&d)[6]) {
     constexpr int J = decltype(jc)::value;
+#ifdef WX_PROBE_2X_VALU
+    {
+      f32x4 dd[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) { dd[b] = d[b]; asm volatile("" : "+v"(dd[b])); }
+      const f32x4 v2 = wx4_pos<J>(dd);
+      h4 hi2, lo2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hi2[e] = (_Float16)v2[e]; lo2[e] = (_Float16)(v2[e] - (float)hi2[e]); }
+      asm volatile("" ::"v"(hi2), "v"(lo2));
+    }
+#endif
     const f32x4 v = wx4_pos<J>(d);
     h4 hi, lo;
 #pragma unroll
@@ -187,8 +205,15 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       hi[e] = (_Float16)v[e];
       lo[e] = (_Float16)(v[e] - (float)hi[e]);
     }
+#ifdef WX_PROBE_NO_LDSW
+    asm volatile("" ::"v"(hi), "v"(lo));
+#else
     *reinterpret_cast<h4*>(v_lds + J * WX_POS + it0.dst) = hi;
     *reinterpret_cast<h4*>(v_lds + J * WX_POS + WX_PLANE + it0.dst) = lo;
+#ifdef WX_PROBE_2X_LDSW
+    asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" ::"v"(it0.dst), "v"(hi), "v"(lo), "n"(J * WX_POS), "n"(J * WX_POS + WX_PLANE) : "memory");
+#endif
+#endif
   };
   auto put_halo = [&](auto jwc, const float (&dh)[6]) {
     constexpr int JW = decltype(jwc)::value;
@@ -198,8 +223,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       if (wx4_coef(JW, b) != 0.f || wx4_coef(JW + 3, b) != 0.f) v = fmaf(hc[JW][b], dh[b], v);
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (float)hi);
+#ifdef WX_PROBE_NO_LDSW
+    asm volatile("" ::"v"(hi), "v"(lo));
+#else
     *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + ith.dst) = hi;
     *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + WX_PLANE + ith.dst) = lo;
+#endif
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -222,11 +251,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     poff[i] = __builtin_amdgcn_readfirstlane((r2 >> 1) * (int)slab_bytes + jq * (3 * 3 * 2048) + dq * 2048 + (r2 & 1) * 1024);
     pdst[i] = __builtin_amdgcn_readfirstlane(qd * 1024);
   }
-  auto dma_stage = [&](int src_off, char* wb) {            // src_off = chunk * 36 KB + ji * 6 KB
-#pragma unroll
-    for (int i = 0; i < NDI; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wcb + src_off + poff[i]),
-                                       (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, 0, 0);
+  auto dma_piece = [&](int i, int src_off, char* wb) {      // src_off = chunk * 36 KB + ji * 6 KB
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wcb + src_off + poff[i]),
+                                     (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, 0, 0);
   };
 
   // ---- fragment addressing
@@ -248,21 +275,90 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       for (int r = 0; r < 16; ++r) acc[j][nr][r] = 0.f;
 
   // ---- prologue: weights of stage 0 by DMA; chunk 0's pixels -> positions {0,3} and {1,4} ({2,5} are written by stage 0 itself)
-  dma_stage(0, w_lds);
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds);
   f32x4 d0[6];
   float dh[6];
-  load_raw(d0, dh, 0);
-  preact(d0, dh);
+#pragma unroll
+  for (int b = 0; b < 6; ++b) load_px(d0, b, 0);
+  load_halo(dh, 0);
+#pragma unroll
+  for (int b = 0; b < 6; ++b) preact_px(d0, b);
+  preact_halo(dh);
   put(I0{}, d0); put(I3{}, d0); put(I1{}, d0); put(I4{}, d0);
   put_halo(I0{}, dh); put_halo(I1{}, dh);
   __syncthreads();
   TSTAMP(1);
 
-  // One stage = positions {ji, 3+ji} of chunk c: NG = 3*NREP groups (dy, slab) of three MFMAs.  d0 / dh hold the pixels of the chunk
-  // whose V planes are being written: c itself in stage 0 (planes {2,5}), c+1 in stages 1 and 2 (planes {0,3}, {1,4}; the last chunk
-  // rewrites its own dead planes).  The body is ONE basic block: fragments are read one group ahead into distinct registers and the
-  // staging arithmetic / LDS writes / loads are threaded between the MFMAs by sched_group_barrier (a wave issues in order and an MFMA
-  // holds the pipe for 32 cycles).
+#ifdef VIRNET_F16_TIMING
+  long long wx_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long wx_tl = (long long)__builtin_amdgcn_s_memtime();
+#endif
+  // One stage = positions {ji, 3+ji} of chunk c: NG = 3*NREP groups (dy, slab) of three MFMAs into one accumulator block.  A wave
+  // issues in order, so the order of issue is written out: per group [fragment reads of the NEXT group] [one piece of the staging
+  // work] [the three MFMAs], fenced by sched_barrier (left to itself the scheduler sinks every read to its use and clumps the VALU
+  // work); the partner wave of the SIMD fills the matrix pipe while this one does a piece.  Staging work of the chunk d whose V
+  // planes are being replaced, as nine pieces per stage:
+  //   stage 0 (d = c):   [DMA] positions {2,5} + halo, then the pixels of chunk c+1 are requested (d0 / dh are free again)
+  //   stage 1 (d = c+1): pre-activation FIRST (the only VMEM operations pending at that point are the pixel loads: the compiler's
+  //                      wait before their first use is a vmcnt(0), and it must not catch this stage's DMA pieces), [DMA], {0,3} + halo
+  //   stage 2 (d = c+1): [DMA] positions {1,4} + halo
+  // The end-of-stage wait of stage 0 leaves the pixel loads in flight: s_waitcnt vmcnt(pixel loads) covers the DMA pieces, which are
+  // issued before them.
+  constexpr int NPX = 12 + (PRE == 2 ? 4 : 0);      // VMEM instructions of one chunk's pixel (+ SFT vector) loads
+  auto dma_pieces = [&](int i0, int i1, int src_off, char* wn) {
+#ifndef WX_PROBE_NO_DMA
+#pragma unroll
+    for (int i = i0; i < i1 && i < NDI; ++i) dma_piece(i, src_off, wn);
+#ifdef WX_PROBE_2X_DMA
+#pragma unroll
+    for (int i = i0; i < i1 && i < NDI; ++i) dma_piece(i, src_off, wn);
+#endif
+#endif
+  };
+  auto piece = [&](auto jic, auto kc, int c, int cn, int src_off, char* wn) {
+    constexpr int ji = decltype(jic)::value, k = decltype(kc)::value;
+    if constexpr (ji == 0) {
+      if constexpr (k == 0) { dma_pieces(0, NDI, src_off, wn); }
+#ifndef WX_PROBE_NO_PUT
+      if constexpr (k == 0) put(I2{}, d0);
+      if constexpr (k == 1) put(I5{}, d0);
+      if constexpr (k == 2) put_halo(I2{}, dh);
+#endif
+#ifndef WX_PROBE_NO_LOADS
+      if constexpr (k == 2) { load_px(d0, 0, cn); load_px(d0, 1, cn); load_px(d0, 2, cn); }
+      if constexpr (k == 3) { load_px(d0, 3, cn); load_px(d0, 4, cn); load_px(d0, 5, cn); }
+      if constexpr (k == 4) load_halo(dh, cn);
+#endif
+    } else if constexpr (ji == 1) {
+#ifndef WX_PROBE_NO_PUT
+      if constexpr (k == 0) { preact_px(d0, 0); preact_px(d0, 1); }
+      if constexpr (k == 1) { preact_px(d0, 2); preact_px(d0, 3); }
+      if constexpr (k == 2) { preact_px(d0, 4); preact_px(d0, 5); preact_halo(dh); }
+#endif
+      if constexpr (k == 3) dma_pieces(0, 2, src_off, wn);
+      if constexpr (k == 4) dma_pieces(2, 4, src_off, wn);
+      if constexpr (k == 5) dma_pieces(4, 6, src_off, wn);
+#ifndef WX_PROBE_NO_PUT
+      if constexpr (k == 4) put(I0{}, d0);
+      if constexpr (k == 6) put(I3{}, d0);
+      if constexpr (k == 7) put_halo(I0{}, dh);
+#endif
+    } else {
+      if constexpr (k == 0) dma_pieces(0, 2, src_off, wn);
+      if constexpr (k == 1) dma_pieces(2, 4, src_off, wn);
+      if constexpr (k == 2) dma_pieces(4, 6, src_off, wn);
+#ifndef WX_PROBE_NO_PUT
+      if constexpr (k == 3) put(I1{}, d0);
+      if constexpr (k == 5) put(I4{}, d0);
+      if constexpr (k == 6) put_halo(I1{}, dh);
+#endif
+    }
+  };
+  // The two waves of a SIMD (w and w+4) run a stage in opposite order -- staging then MFMAs / MFMAs then staging -- so that one feeds
+  // the matrix pipe while the other works through its VALU chains (transform -> split is a dependent chain of ~8 operations per value:
+  // issued between the MFMAs of the same wave it is latency-bound and costs ~15 cycles per instruction, measured).
+  const bool mfma_first = wave >= 4;
   auto stage = [&](int c, auto jic) {
     constexpr int ji = decltype(jic)::value;
     constexpr int NG = 3 * NREP;
@@ -270,67 +366,74 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
     char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
     const int cn = min(c + 1, nch - 1);
-    const char* const vb = vjt + ji * WX_POS;
-    h8 ah[NG], al[NG], bh[3], bl[3];
-    auto rd_a = [&](int g) {
-      ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
-      al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
-    };
-    auto rd_b = [&](int dy) {
-      bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
-      bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
-    };
-    SB();
-    rd_a(0);
-    rd_b(0);
     // next stage's weights (the last stage fetches itself again into the idle buffer)
-    dma_stage(ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : cn * WX_CHUNK_BYTES + (c + 1 < nch ? 0 : 2 * 6144), wn);
-    if constexpr (ji == 0) {
-      put(I2{}, d0); put(I5{}, d0);
-      put_halo(I2{}, dh);
-      load_raw(d0, dh, cn);
-    } else if constexpr (ji == 1) {
-      preact(d0, dh);
-      put(I0{}, d0); put(I3{}, d0);
-      put_halo(I0{}, dh);
-    } else {
-      put(I1{}, d0); put(I4{}, d0);
-      put_halo(I1{}, dh);
-    }
+    const int src_off = ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : cn * WX_CHUNK_BYTES + (c + 1 < nch ? 0 : 2 * 6144);
+    const char* const vb = vjt + ji * WX_POS;
+    auto do_staging = [&]() {
+      SB();
+#ifndef WX_PROBE_NO_STAGE
+      piece(jic, I0{}, c, cn, src_off, wn); piece(jic, I1{}, c, cn, src_off, wn); piece(jic, I2{}, c, cn, src_off, wn);
+      piece(jic, I3{}, c, cn, src_off, wn); piece(jic, I4{}, c, cn, src_off, wn); piece(jic, I5{}, c, cn, src_off, wn);
+      piece(jic, std::integral_constant<int, 6>{}, c, cn, src_off, wn); piece(jic, std::integral_constant<int, 7>{}, c, cn, src_off, wn);
+      piece(jic, std::integral_constant<int, 8>{}, c, cn, src_off, wn);
+#endif
+      SB();
+    };
+    auto do_mfma = [&]() {
+      h8 ah[NG], al[NG], bh[3], bl[3];
+      auto rd_a = [&](int g) {
+        ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
+        al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
+      };
+      auto rd_b = [&](int dy) {
+        bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
+        bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
+      };
+      SB();
+      rd_a(0);
+      rd_b(0);
+      SB();
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int dy = g / NREP, nr = g - dy * NREP;
-      if (g + 1 < NG) {
-        rd_a(g + 1);
-        if ((g + 1) % NREP == 0) rd_b((g + 1) / NREP);
+      for (int g = 0; g < NG; ++g) {
+        const int dy = g / NREP, nr = g - dy * NREP;
+        if (g + 1 < NG) {
+          rd_a(g + 1);
+          if ((g + 1) % NREP == 0) rd_b((g + 1) / NREP);
+        }
+        SB();
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[dy], acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[dy], acc[ji][nr], 0, 0, 0);
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[dy], acc[ji][nr], 0, 0, 0);
+        SB();
       }
-      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[dy], acc[ji][nr], 0, 0, 0);
-      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[dy], acc[ji][nr], 0, 0, 0);
-      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[dy], acc[ji][nr], 0, 0, 0);
+    };
+    // (ONE copy of the MFMA code, the staging code before or after it: the accumulators pass through the conditional blocks untouched)
+    if (!mfma_first) do_staging();
+    do_mfma();
+    if (mfma_first) do_staging();
+    // end of stage: this wave's DMA pieces have landed (they are older than the pixel loads of stage 0, which stay in flight), its
+    // LDS writes are done; then the workgroup barrier
+#ifdef VIRNET_F16_TIMING
+    {  // wave 0 accounts its stage: work until the waits, the vmcnt drain, the barrier
+      const long long ta = (long long)__builtin_amdgcn_s_memtime();
+      if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPX) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const long long tb = (long long)__builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const long long tl = (long long)__builtin_amdgcn_s_memtime();
+      asm volatile("s_barrier" ::: "memory");
+      const long long tc = (long long)__builtin_amdgcn_s_memtime();
+      wx_t[ji * 4 + 0] += ta - wx_tl; wx_t[ji * 4 + 1] += tb - ta; wx_t[ji * 4 + 2] += tl - tb; wx_t[ji * 4 + 3] += tc - tl;
+      wx_tl = tc;
     }
-    // ---- the order of issue
-    constexpr int NVM = ji == 0 ? 12 + (PRE == 2 ? 4 : 0) : 0;        // pixel (+ SFT vector) loads of stage 0
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x010, NDI, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, WX_HEAD_VALU, 0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const bool rd = g + 1 < NG, rdb = rd && (g + 1) % NREP == 0;
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
-      if (g * 2 < NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
-      if (g * 2 + 1 < NVM) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (rdb) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, WX_GAP_VALU, 0);
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
-    SB();
-    __syncthreads();
+#else
+#if defined(WX_PROBE_NO_LOADS)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#endif
   };
   for (int c = 0; c < nch; ++c) {
     stage(c, I0{});
@@ -338,6 +441,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     stage(c, I2{});
   }
   TSTAMP(2);
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && (tid & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a.tlog[(size_t)a.ntiles * ncb * 16 + ((size_t)blockIdx.x * 8 + wave) * 16 + i] = wx_t[i];
+  }
+#endif
 
   // ---- epilogue.  Per slab: wave (jt, rb) writes three blocks of [column = (row, x-tile)][32 channels] records
   //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
