@@ -1,0 +1,202 @@
+#!/usr/bin/env python
+"""Static issue schedule of one stage of conv_wx4_kernel (csrc/conv_f16_wx4.hip) -> csrc/conv_f16_wx4_sched.inc.
+
+A stage of the kernel is 9*NREP MFMAs of one wave.  A wave issues in order and an MFMA keeps the matrix pipe busy for 32 cycles, so
+everything else the wave has to do in that stage -- fragment reads, the Winograd input transform + fp16 split of the next chunk's
+pixels, pixel loads, weight DMA -- is cut into micro-operations (the lambdas of the kernel) and placed into the SLOTS between the
+MFMAs: a dependent micro-operation lands at least one slot (= one MFMA, >= 32 cycles) behind its producer, so no VALU latency is
+exposed, fragment reads land LDS_LAT slots ahead of the MFMA that consumes them, and no slot carries more than CAP issue units.
+hipcc's own scheduler, given the same code as one block, sinks every read to its use and clumps the VALU work (tried: plain code,
+sched_group_barrier pipelines); here every slot is fenced with sched_barrier and the placement is decided by this script.
+
+Micro-operations (names = lambdas in the kernel; X = put context 0/1, J = Winograd position, b = pixel, g = MFMA group (dy, slab)):
+  rdA(g) rdB(dy)            fragment reads (LDS)
+  pA/pB/pV(X,J)             the rows of B^T on the thread's 6 pixels x 4 channels      pHi/pSub/pLo(X) fp16 split   pSt(X,J) LDS store
+  hSa/hSb/hV(JW) hHi hSub hLo hSt(JW)   the same for the thread's one halo value
+  prM(b) prX(b) prHa prHb   pre-activation (stage 1)            ldp(b) ldh(b) ldsft   pixel loads of the next chunk (stage 0)
+  dma(i)                    one 1-KB piece of the next stage's weights
+Stage 0 writes positions {2,5} (+ halo pair 2) and then requests the next chunk's pixels (the DMA pieces are issued BEFORE them: the
+end-of-stage wait counts on it); stage 1 pre-activates -- every first touch of a loaded register before the stage's first DMA piece,
+because the compiler's wait for a pixel load becomes vmcnt(0) once a DMA piece is pending -- and writes {0,3}; stage 2 writes {1,4}.
+
+Usage: python tools/gen_wx4_sched.py > virnet_amd/csrc/conv_f16_wx4_sched.inc      (knobs: CAP, LDS_LAT below)"""
+import sys
+
+CAP = 6        # issue units per slot (an MFMA hides about five single-issue instructions)
+LDS_LAT = 4    # slots between a fragment read and the MFMA that consumes it
+HEAD_CAP = 14  # slot 0 sits behind the barrier, in front of the first MFMA which waits for its fragments anyway
+
+
+class Op:
+    def __init__(self, name, code, cost, deps=(), earliest=0, kind="valu"):
+        self.name, self.code, self.cost, self.deps, self.earliest, self.kind = name, code, cost, list(deps), earliest, kind
+        self.slot = None
+
+
+def I(n):
+    return "WX_I(%d)" % n
+
+
+def put_ops(x, j, ops):
+    """micro-ops of one position for put context x; returns the names of the ops that read d0 (for the load WAR edges)"""
+    rd = ["pA%d" % x]
+    ops.append(Op("pA%d" % x, "pA(%s, %s);" % (I(x), I(j)), 2))
+    if j in (1, 2, 3, 4):
+        ops.append(Op("pB%d" % x, "pB(%s, %s);" % (I(x), I(j)), 2))
+        rd.append("pB%d" % x)
+        ops.append(Op("pV%d" % x, "pV(%s, %s);" % (I(x), I(j)), 2, [("pA%d" % x, 1), ("pB%d" % x, 1)]))
+    else:
+        ops.append(Op("pV%d" % x, "pV(%s, %s);" % (I(x), I(j)), 2, [("pA%d" % x, 1)]))
+        rd.append("pV%d" % x)
+    ops.append(Op("pHi%d" % x, "pHi(%s);" % I(x), 2, [("pV%d" % x, 1)]))
+    ops.append(Op("pSub%d" % x, "pSub(%s);" % I(x), 4, [("pHi%d" % x, 1)]))
+    ops.append(Op("pLo%d" % x, "pLo(%s);" % I(x), 2, [("pSub%d" % x, 1)]))
+    ops.append(Op("pSt%d" % x, "pSt(%s, %s);" % (I(x), I(j)), 2, [("pLo%d" % x, 1)], kind="ldsw"))
+    return rd
+
+
+def halo_ops(jw, ops):
+    ops.append(Op("hSa", "hSa(%s);" % I(jw), 3))
+    ops.append(Op("hSb", "hSb(%s);" % I(jw), 3))
+    ops.append(Op("hV", "hV();", 1, [("hSa", 1), ("hSb", 1)]))
+    ops.append(Op("hHi", "hHi();", 1, [("hV", 1)]))
+    ops.append(Op("hSub", "hSub();", 2, [("hHi", 1)]))
+    ops.append(Op("hLo", "hLo();", 1, [("hSub", 1)]))
+    ops.append(Op("hSt", "hSt(%s);" % I(jw), 2, [("hLo", 1)], kind="ldsw"))
+    return ["hSa", "hSb"]
+
+
+def build(nrep, ji, pre):
+    ng, nm = 3 * nrep, 9 * nrep
+    ndi = (12 * nrep + 7) // 8
+    ops = []
+    # fragment reads: deadline = the first MFMA that uses them
+    reads = []
+    for dy in range(3):
+        reads.append(("rdB%d" % dy, "rdB(%s);" % I(dy), 3 * nrep * dy))
+    for g in range(ng):
+        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), 3 * g))
+    for name, code, use in sorted(reads, key=lambda r: r[2]):
+        o = Op(name, code, 2, kind="ldsr")
+        o.deadline = max(0, use - LDS_LAT)
+        ops.append(o)
+    dma = [Op("dma%d" % i, "dma(%s);" % I(i), 4, kind="dma") for i in range(ndi)]
+    stg = []
+    if ji == 0:
+        rd = put_ops(0, 2, stg) + put_ops(1, 5, stg) + halo_ops(2, stg)
+        lds = []
+        for b in range(6):
+            lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(r, 1) for r in rd] + [(d.name, 1) for d in dma], kind="vmem"))
+        for b in range(6):
+            lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [(r, 1) for r in rd] + [(d.name, 1) for d in dma], kind="vmem"))
+        if pre == 2:
+            lds.append(Op("ldsft", "ldsft();", 4, [(d.name, 1) for d in dma], kind="vmem"))
+        # the DMA pieces go first (they must be older than the pixel loads), one per slot from slot 1 on
+        for i, d in enumerate(dma):
+            d.earliest = 1 + i
+        ops += dma + stg + lds
+    elif ji == 1:
+        first = []
+        if pre >= 1:
+            for b in range(6):
+                # (prM(b) writes the temporary that prX(b-2) reads)
+                stg.append(Op("prM%d" % b, "prM(%s);" % I(b), 2 if pre == 1 else 4, [("prX%d" % (b - 2), 1)] if b >= 2 else []))
+                first.append("prM%d" % b)
+                if b >= 1:
+                    stg.append(Op("prX%d" % (b - 1), "prX(%s);" % I(b - 1), 4 if pre == 1 else 8, [("prM%d" % (b - 1), 1)]))
+            stg.append(Op("prX5", "prX(%s);" % I(5), 4 if pre == 1 else 8, [("prM5", 1)]))
+            stg.append(Op("prHa", "prHa();", 6))
+            stg.append(Op("prHb", "prHb();", 6))
+            first += ["prHa", "prHb"]
+            pdeps = [("prX%d" % b, 1) for b in range(6)]
+            hdeps = [("prHa", 1), ("prHb", 1)]
+        else:
+            # no pre-activation: the first touch of the loaded registers is a cheap copy-free marker (mask only when PRE == 2)
+            for b in range(6):
+                stg.append(Op("prX%d" % b, "prX(%s);" % I(b), 1))
+                first.append("prX%d" % b)
+            stg.append(Op("prHa", "prHa();", 1))
+            stg.append(Op("prHb", "prHb();", 1))
+            first += ["prHa", "prHb"]
+            pdeps = [("prX%d" % b, 1) for b in range(6)]
+            hdeps = [("prHa", 1), ("prHb", 1)]
+        p0 = len(stg)
+        put_ops(0, 0, stg)
+        put_ops(1, 3, stg)
+        halo_ops(0, stg)
+        for o in stg[p0:]:
+            if o.name in ("pA0", "pA1", "pB1", "pV0"):
+                o.deps += pdeps
+            if o.name in ("hSa", "hSb"):
+                o.deps += hdeps
+        for d in dma:
+            d.deps += [(f, 1) for f in first]
+        ops += stg[:p0] + dma + stg[p0:]          # (the DMA pieces right behind the first touches, ahead of the position work)
+    else:
+        put_ops(0, 1, stg)
+        put_ops(1, 4, stg)
+        halo_ops(1, stg)
+        for i, d in enumerate(dma):
+            d.earliest = 1 + 2 * i
+        ops += dma + stg
+    return ops, nm
+
+
+def schedule(ops, nm):
+    load = [0] * (nm + 1)
+    by = {o.name: o for o in ops}
+
+    def cap(s):
+        return HEAD_CAP if s == 0 else CAP
+
+    # 1. fragment reads at their deadlines (moved earlier if the slot is full)
+    for o in ops:
+        if o.kind == "ldsr":
+            s = o.deadline
+            while s > 0 and load[s] + o.cost > cap(s):
+                s -= 1
+            o.slot = s
+            load[s] += o.cost
+    # 2. everything else in list order: earliest slot that satisfies its dependences and has room
+    for o in ops:
+        if o.slot is not None:
+            continue
+        s = o.earliest
+        for d, lat in o.deps:
+            assert by[d].slot is not None, (o.name, d)
+            s = max(s, by[d].slot + lat)
+        while s < nm and load[s] + min(o.cost, CAP) > cap(s):      # (an operation larger than a slot takes an empty one)
+            s += 1
+        s = min(s, nm)
+        o.slot = s
+        load[s] += o.cost
+    return load
+
+
+def emit(nrep, ji, pre, out):
+    ops, nm = build(nrep, ji, pre)
+    load = schedule(ops, nm)
+    order = {"ldsr": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
+    out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre))
+    for s in range(nm + 1):
+        here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])
+        line = "  SB(); " + " ".join(o.code for o in here) + " SB();"
+        if s < nm:
+            line += " mfma(%s, %s);" % (I(s // 3), I(s % 3))
+        out.append(line + " \\")
+    out.append("  /* issue units per slot: %s */" % " ".join(str(x) for x in load))
+    out.append("")
+
+
+def main():
+    out = ["// GENERATED by tools/gen_wx4_sched.py (CAP=%d, LDS_LAT=%d, HEAD_CAP=%d) -- do not edit; see that script for the model." % (CAP, LDS_LAT, HEAD_CAP),
+           "// WX4_STAGE_<NREP>_<ji>_<PRE>: the body of one stage of conv_wx4_kernel as fenced issue slots, one per MFMA.", ""]
+    for nrep in (1, 2, 3):
+        for ji in range(3):
+            for pre in (0, 1, 2):
+                emit(nrep, ji, pre, out)
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,7 @@
 // blocks ([pixel][channel] records) to LDS and each thread finishes (pixel, channel quad) items from two or three of them: the same
 // round trip also turns the tile around for 128-byte runs in the NHWC store.  Inverse scale, bias, mask, residual, activation as conv_f16.hip.
 #include "conv_f16_common.h"
+#include "conv_f16_wx4_sched.inc"
 #include <cstdlib>
 #include <type_traits>
 
@@ -66,6 +67,21 @@ __device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
 __device__ __forceinline__ float vmax(float a, float b) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// two fp32 -> packed fp16x2, round to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned cvtpk(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 r = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, r);
+}
+// v - float(half HALF of hpk) in ONE VALU operation (v_fma_mix_f32 reads the fp16 half directly); exact like the subtraction
+template <int HALF>
+__device__ __forceinline__ float subhi(float v, unsigned hpk) {
+  float r;
+  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
   return r;
 }
 
@@ -151,92 +167,133 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const float in_slope_eff = a.in_slope;
   f32x4 sm = f32x4{1.f, 1.f, 1.f, 1.f}, sa = f32x4{0.f, 0.f, 0.f, 0.f};     // SFT vectors of the chunk in d0 / dh (PRE == 2)
   float smh = 1.f, sah = 0.f;
-  // pixel b of the main item / of the halo value.  (A pixel outside the image is read at offset 0 and masked afterwards: the
-  // descriptor's range check sees the vector offset alone, so an item whose FIRST pixel lies left of / above the image cannot carry
-  // its offset in wrapped form.)
-  auto load_px = [&](f32x4 (&d)[6], int b, int chunk) {
-    d[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : 0u, chunk * 64, 0));
+  // ---- micro-operations of the staging work; tools/gen_wx4_sched.py places them into the issue slots between the MFMAs of a stage.
+  // A pixel outside the image is requested at an offset beyond the descriptor's range: the load returns 0 (and lrelu(0) = 0: no mask;
+  // with SFT vectors the mask is applied after the modulation).  The range check sees the vector offset alone, so the pixel's offset is
+  // formed per load instead of riding in the scalar offset (an item whose FIRST pixel lies left of the image would wrap).
+  f32x4 d0[6];
+  float dh[6];
+  int ld_so = 0;                                   // byte offset of the chunk whose pixels are being requested
+  constexpr unsigned OOB = 0x80000000u;
+  auto ldp = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    d0[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : OOB, ld_so, 0));
   };
-  auto load_halo = [&](float (&dh)[6], int chunk) {
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-      dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : 0u, chunk * 64, 0));
+  auto ldh = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    dh[b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, ((ith.inb >> b) & 1u) ? ith.voff + b * pxb : OOB, ld_so, 0));
+  };
+  auto ldsft = [&]() {
     if constexpr (PRE == 2) {
-      sm = *reinterpret_cast<const f32x4*>(imul + chunk * 16 + 4 * sq);
-      sa = *reinterpret_cast<const f32x4*>(iadd + chunk * 16 + 4 * sq);
-      smh = imul[chunk * 16 + hch];
-      sah = iadd[chunk * 16 + hch];
+      sm = *reinterpret_cast<const f32x4*>(imul + (ld_so >> 2) + 4 * sq);
+      sa = *reinterpret_cast<const f32x4*>(iadd + (ld_so >> 2) + 4 * sq);
+      smh = imul[(ld_so >> 2) + hch];
+      sah = iadd[(ld_so >> 2) + hch];
     }
   };
-  // pre-activation, then zero outside the image ("pad after activation")
-  auto preact_px = [&](f32x4 (&d)[6], int b) {
-    f32x4 v = d[b];
-    if constexpr (PRE == 2) v = v * sm + sa;
-    if constexpr (PRE >= 1) v = f32x4{vmax(v.x, v.x * in_slope_eff), vmax(v.y, v.y * in_slope_eff), vmax(v.z, v.z * in_slope_eff), vmax(v.w, v.w * in_slope_eff)};
-    d[b] = ((it0.inb >> b) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  // pre-activation (AttResUNet.py:54-55): prM forms slope*x (the first touch of the loaded register), prX takes the maximum one slot later
+  f32x4 pt[2];
+  auto prM = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if constexpr (PRE == 2) d0[b] = d0[b] * sm + sa;
+    pt[b & 1] = d0[b] * in_slope_eff;
   };
-  auto preact_halo = [&](float (&dh)[6]) {
+  auto prX = [&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    if constexpr (PRE == 0) {
+      f32x4 t = d0[b];                                // (the compiler's wait for this load belongs here, ahead of the stage's DMA pieces)
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(t));
+#endif
+      d0[b] = t;
+    } else {
+      const f32x4 t = pt[b & 1];
+      f32x4 v = f32x4{vmax(d0[b].x, t.x), vmax(d0[b].y, t.y), vmax(d0[b].z, t.z), vmax(d0[b].w, t.w)};
+      if constexpr (PRE == 2) v = ((it0.inb >> b) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      d0[b] = v;
+    }
+  };
+  auto prH = [&](int b0) {
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
+    for (int b = b0; b < b0 + 3; ++b) {
       float u = dh[b];
+      if constexpr (PRE == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(u));
+#endif
+      }
       if constexpr (PRE == 2) u = u * smh + sah;
       if constexpr (PRE >= 1) u = vmax(u, u * in_slope_eff);
-      dh[b] = ((ith.inb >> b) & 1u) ? u : 0.f;
+      if constexpr (PRE == 2) u = ((ith.inb >> b) & 1u) ? u : 0.f;
+      dh[b] = u;
     }
   };
-  auto put = [&](auto jc, const f32x4 (&d)[6]) {
-    constexpr int J = decltype(jc)::value;
-#ifdef WX_PROBE_2X_VALU
-    {
-      f32x4 dd[6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) { dd[b] = d[b]; asm volatile("" : "+v"(dd[b])); }
-      const f32x4 v2 = wx4_pos<J>(dd);
-      h4 hi2, lo2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { hi2[e] = (_Float16)v2[e]; lo2[e] = (_Float16)(v2[e] - (float)hi2[e]); }
-      asm volatile("" ::"v"(hi2), "v"(lo2));
-    }
-#endif
-    const f32x4 v = wx4_pos<J>(d);
-    h4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hi[e] = (_Float16)v[e];
-      lo[e] = (_Float16)(v[e] - (float)hi[e]);
-    }
-#ifdef WX_PROBE_NO_LDSW
-    asm volatile("" ::"v"(hi), "v"(lo));
-#else
-    *reinterpret_cast<h4*>(v_lds + J * WX_POS + it0.dst) = hi;
-    *reinterpret_cast<h4*>(v_lds + J * WX_POS + WX_PLANE + it0.dst) = lo;
-#ifdef WX_PROBE_2X_LDSW
-    asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%4" ::"v"(it0.dst), "v"(hi), "v"(lo), "n"(J * WX_POS), "n"(J * WX_POS + WX_PLANE) : "memory");
-#endif
-#endif
+  auto prHa = [&]() { prH(0); };
+  auto prHb = [&]() { prH(3); };
+  // one Winograd position of the main item: rows of B^T in two or three steps, exact fp16 split in three, one LDS store
+  struct PutCtx { f32x4 a, b, v; unsigned h0, h1, l0, l1; };
+  PutCtx pc[2];
+  auto pA = [&](auto xc, auto jc) {
+    constexpr int X = decltype(xc)::value, J = decltype(jc)::value;
+    if constexpr (J == 0) pc[X].a = 4.f * d0[0] + d0[4];
+    else if constexpr (J == 5) pc[X].a = 4.f * d0[1] + d0[5];
+    else if constexpr (J == 1 || J == 2) pc[X].a = d0[4] - 4.f * d0[2];
+    else pc[X].a = d0[4] - d0[2];
   };
-  auto put_halo = [&](auto jwc, const float (&dh)[6]) {
+  auto pB = [&](auto xc, auto jc) {
+    constexpr int X = decltype(xc)::value, J = decltype(jc)::value;
+    if constexpr (J == 1 || J == 2) pc[X].b = d0[3] - 4.f * d0[1];
+    else pc[X].b = d0[3] - d0[1];
+  };
+  auto pV = [&](auto xc, auto jc) {
+    constexpr int X = decltype(xc)::value, J = decltype(jc)::value;
+    if constexpr (J == 0) pc[X].v = pc[X].a - 5.f * d0[2];
+    else if constexpr (J == 5) pc[X].v = pc[X].a - 5.f * d0[3];
+    else if constexpr (J == 1) pc[X].v = pc[X].a + pc[X].b;
+    else if constexpr (J == 2) pc[X].v = pc[X].a - pc[X].b;
+    else if constexpr (J == 3) pc[X].v = pc[X].a + 2.f * pc[X].b;
+    else pc[X].v = pc[X].a - 2.f * pc[X].b;
+  };
+  auto pHi = [&](auto xc) {
+    constexpr int X = decltype(xc)::value;
+    pc[X].h0 = cvtpk(pc[X].v.x, pc[X].v.y);
+    pc[X].h1 = cvtpk(pc[X].v.z, pc[X].v.w);
+  };
+  auto pSub = [&](auto xc) {
+    constexpr int X = decltype(xc)::value;
+    pc[X].a = f32x4{subhi<0>(pc[X].v.x, pc[X].h0), subhi<1>(pc[X].v.y, pc[X].h0), subhi<0>(pc[X].v.z, pc[X].h1), subhi<1>(pc[X].v.w, pc[X].h1)};
+  };
+  auto pLo = [&](auto xc) {
+    constexpr int X = decltype(xc)::value;
+    pc[X].l0 = cvtpk(pc[X].a.x, pc[X].a.y);
+    pc[X].l1 = cvtpk(pc[X].a.z, pc[X].a.w);
+  };
+  auto pSt = [&](auto xc, auto jc) {
+    constexpr int X = decltype(xc)::value, J = decltype(jc)::value;
+    *reinterpret_cast<uint2*>(v_lds + J * WX_POS + it0.dst) = make_uint2(pc[X].h0, pc[X].h1);
+    *reinterpret_cast<uint2*>(v_lds + J * WX_POS + WX_PLANE + it0.dst) = make_uint2(pc[X].l0, pc[X].l1);
+  };
+  // the thread's halo value of position pair JW
+  float hv = 0.f, hw = 0.f;
+  _Float16 hhi = (_Float16)0.f, hlo = (_Float16)0.f;
+  auto hSa = [&](auto jwc) {
     constexpr int JW = decltype(jwc)::value;
-    float v = 0.f;
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-      if (wx4_coef(JW, b) != 0.f || wx4_coef(JW + 3, b) != 0.f) v = fmaf(hc[JW][b], dh[b], v);
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
-#ifdef WX_PROBE_NO_LDSW
-    asm volatile("" ::"v"(hi), "v"(lo));
-#else
-    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + ith.dst) = hi;
-    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + WX_PLANE + ith.dst) = lo;
-#endif
+    hv = fmaf(hc[JW][3], dh[3], fmaf(hc[JW][1], dh[1], hc[JW][0] * dh[0]));
   };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  using I4 = std::integral_constant<int, 4>;
-  using I5 = std::integral_constant<int, 5>;
-
+  auto hSb = [&](auto jwc) {
+    constexpr int JW = decltype(jwc)::value;
+    hw = fmaf(hc[JW][5], dh[5], fmaf(hc[JW][4], dh[4], hc[JW][2] * dh[2]));
+  };
+  auto hV = [&]() { hv += hw; };
+  auto hHi = [&]() { hhi = (_Float16)hv; };
+  auto hSub = [&]() { hw = hv - (float)hhi; };
+  auto hLo = [&]() { hlo = (_Float16)hw; };
+  auto hSt = [&](auto jwc) {
+    constexpr int JW = decltype(jwc)::value;
+    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + ith.dst) = hhi;
+    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + WX_PLANE + ith.dst) = hlo;
+  };
+#define WX_I(n) std::integral_constant<int, n>{}
   // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB].
   // Waves without a piece in the last round move their previous piece again (same bytes to the same place): no branch.
   const size_t slab_bytes = (size_t)nch * WX_CHUNK_BYTES;
@@ -277,91 +334,33 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // ---- prologue: weights of stage 0 by DMA; chunk 0's pixels -> positions {0,3} and {1,4} ({2,5} are written by stage 0 itself)
 #pragma unroll
   for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds);
-  f32x4 d0[6];
-  float dh[6];
-#pragma unroll
-  for (int b = 0; b < 6; ++b) load_px(d0, b, 0);
-  load_halo(dh, 0);
-#pragma unroll
-  for (int b = 0; b < 6; ++b) preact_px(d0, b);
-  preact_halo(dh);
-  put(I0{}, d0); put(I3{}, d0); put(I1{}, d0); put(I4{}, d0);
-  put_halo(I0{}, dh); put_halo(I1{}, dh);
+  ldp(WX_I(0)); ldp(WX_I(1)); ldp(WX_I(2)); ldp(WX_I(3)); ldp(WX_I(4)); ldp(WX_I(5));
+  ldh(WX_I(0)); ldh(WX_I(1)); ldh(WX_I(2)); ldh(WX_I(3)); ldh(WX_I(4)); ldh(WX_I(5));
+  ldsft();
+  if constexpr (PRE >= 1) {
+    prM(WX_I(0)); prX(WX_I(0)); prM(WX_I(1)); prX(WX_I(1)); prM(WX_I(2)); prX(WX_I(2));
+    prM(WX_I(3)); prX(WX_I(3)); prM(WX_I(4)); prX(WX_I(4)); prM(WX_I(5)); prX(WX_I(5));
+    prHa(); prHb();
+  }
+  pA(WX_I(0), WX_I(0)); pV(WX_I(0), WX_I(0)); pHi(WX_I(0)); pSub(WX_I(0)); pLo(WX_I(0)); pSt(WX_I(0), WX_I(0));
+  pA(WX_I(1), WX_I(3)); pB(WX_I(1), WX_I(3)); pV(WX_I(1), WX_I(3)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(3));
+  pA(WX_I(0), WX_I(1)); pB(WX_I(0), WX_I(1)); pV(WX_I(0), WX_I(1)); pHi(WX_I(0)); pSub(WX_I(0)); pLo(WX_I(0)); pSt(WX_I(0), WX_I(1));
+  pA(WX_I(1), WX_I(4)); pB(WX_I(1), WX_I(4)); pV(WX_I(1), WX_I(4)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(4));
+  hSa(WX_I(0)); hSb(WX_I(0)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(0));
+  hSa(WX_I(1)); hSb(WX_I(1)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(1));
   __syncthreads();
   TSTAMP(1);
 
-#ifdef VIRNET_F16_TIMING
-  long long wx_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  long long wx_tl = (long long)__builtin_amdgcn_s_memtime();
-#endif
-  // One stage = positions {ji, 3+ji} of chunk c: NG = 3*NREP groups (dy, slab) of three MFMAs into one accumulator block.  A wave
-  // issues in order, so the order of issue is written out: per group [fragment reads of the NEXT group] [one piece of the staging
-  // work] [the three MFMAs], fenced by sched_barrier (left to itself the scheduler sinks every read to its use and clumps the VALU
-  // work); the partner wave of the SIMD fills the matrix pipe while this one does a piece.  Staging work of the chunk d whose V
-  // planes are being replaced, as nine pieces per stage:
-  //   stage 0 (d = c):   [DMA] positions {2,5} + halo, then the pixels of chunk c+1 are requested (d0 / dh are free again)
-  //   stage 1 (d = c+1): pre-activation FIRST (the only VMEM operations pending at that point are the pixel loads: the compiler's
-  //                      wait before their first use is a vmcnt(0), and it must not catch this stage's DMA pieces), [DMA], {0,3} + halo
-  //   stage 2 (d = c+1): [DMA] positions {1,4} + halo
-  // The end-of-stage wait of stage 0 leaves the pixel loads in flight: s_waitcnt vmcnt(pixel loads) covers the DMA pieces, which are
-  // issued before them.
+  // One stage = positions {ji, 3+ji} of chunk c: 3*NREP groups (dy, slab) of three MFMAs into one accumulator block.  The body of a
+  // stage is the generated issue schedule WX4_STAGE_<NREP>_<ji>_<PRE> (conv_f16_wx4_sched.inc): every MFMA sits behind a fenced slot
+  // of fragment reads and micro-operations.  d0 / dh hold the pixels of the chunk whose V planes are being replaced:
+  //   stage 0: positions {2,5} of chunk c (+ halo pair 2); then the pixels of chunk c+1 are requested into the freed registers
+  //   stage 1: pre-activation of chunk c+1, positions {0,3};   stage 2: positions {1,4}    (planes {ji, 3+ji} die with stage ji)
+  // The last chunk re-reads itself and rewrites its own dead planes: no branch in the stage code.  The end-of-stage wait of stage 0
+  // leaves the pixel loads in flight: s_waitcnt vmcnt(pixel loads) covers the DMA pieces, which are issued before them.
   constexpr int NPX = 12 + (PRE == 2 ? 4 : 0);      // VMEM instructions of one chunk's pixel (+ SFT vector) loads
-  auto dma_pieces = [&](int i0, int i1, int src_off, char* wn) {
-#ifndef WX_PROBE_NO_DMA
-#pragma unroll
-    for (int i = i0; i < i1 && i < NDI; ++i) dma_piece(i, src_off, wn);
-#ifdef WX_PROBE_2X_DMA
-#pragma unroll
-    for (int i = i0; i < i1 && i < NDI; ++i) dma_piece(i, src_off, wn);
-#endif
-#endif
-  };
-  auto piece = [&](auto jic, auto kc, int c, int cn, int src_off, char* wn) {
-    constexpr int ji = decltype(jic)::value, k = decltype(kc)::value;
-    if constexpr (ji == 0) {
-      if constexpr (k == 0) { dma_pieces(0, NDI, src_off, wn); }
-#ifndef WX_PROBE_NO_PUT
-      if constexpr (k == 0) put(I2{}, d0);
-      if constexpr (k == 1) put(I5{}, d0);
-      if constexpr (k == 2) put_halo(I2{}, dh);
-#endif
-#ifndef WX_PROBE_NO_LOADS
-      if constexpr (k == 2) { load_px(d0, 0, cn); load_px(d0, 1, cn); load_px(d0, 2, cn); }
-      if constexpr (k == 3) { load_px(d0, 3, cn); load_px(d0, 4, cn); load_px(d0, 5, cn); }
-      if constexpr (k == 4) load_halo(dh, cn);
-#endif
-    } else if constexpr (ji == 1) {
-#ifndef WX_PROBE_NO_PUT
-      if constexpr (k == 0) { preact_px(d0, 0); preact_px(d0, 1); }
-      if constexpr (k == 1) { preact_px(d0, 2); preact_px(d0, 3); }
-      if constexpr (k == 2) { preact_px(d0, 4); preact_px(d0, 5); preact_halo(dh); }
-#endif
-      if constexpr (k == 3) dma_pieces(0, 2, src_off, wn);
-      if constexpr (k == 4) dma_pieces(2, 4, src_off, wn);
-      if constexpr (k == 5) dma_pieces(4, 6, src_off, wn);
-#ifndef WX_PROBE_NO_PUT
-      if constexpr (k == 4) put(I0{}, d0);
-      if constexpr (k == 6) put(I3{}, d0);
-      if constexpr (k == 7) put_halo(I0{}, dh);
-#endif
-    } else {
-      if constexpr (k == 0) dma_pieces(0, 2, src_off, wn);
-      if constexpr (k == 1) dma_pieces(2, 4, src_off, wn);
-      if constexpr (k == 2) dma_pieces(4, 6, src_off, wn);
-#ifndef WX_PROBE_NO_PUT
-      if constexpr (k == 3) put(I1{}, d0);
-      if constexpr (k == 5) put(I4{}, d0);
-      if constexpr (k == 6) put_halo(I1{}, dh);
-#endif
-    }
-  };
-  // The two waves of a SIMD (w and w+4) run a stage in opposite order -- staging then MFMAs / MFMAs then staging -- so that one feeds
-  // the matrix pipe while the other works through its VALU chains (transform -> split is a dependent chain of ~8 operations per value:
-  // issued between the MFMAs of the same wave it is latency-bound and costs ~15 cycles per instruction, measured).
-  const bool mfma_first = wave >= 4;
   auto stage = [&](int c, auto jic) {
     constexpr int ji = decltype(jic)::value;
-    constexpr int NG = 3 * NREP;
     const int s = c * 3 + ji;
     const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
     char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
@@ -369,84 +368,44 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     // next stage's weights (the last stage fetches itself again into the idle buffer)
     const int src_off = ji < 2 ? c * WX_CHUNK_BYTES + (ji + 1) * 6144 : cn * WX_CHUNK_BYTES + (c + 1 < nch ? 0 : 2 * 6144);
     const char* const vb = vjt + ji * WX_POS;
-    auto do_staging = [&]() {
-      SB();
-#ifndef WX_PROBE_NO_STAGE
-      piece(jic, I0{}, c, cn, src_off, wn); piece(jic, I1{}, c, cn, src_off, wn); piece(jic, I2{}, c, cn, src_off, wn);
-      piece(jic, I3{}, c, cn, src_off, wn); piece(jic, I4{}, c, cn, src_off, wn); piece(jic, I5{}, c, cn, src_off, wn);
-      piece(jic, std::integral_constant<int, 6>{}, c, cn, src_off, wn); piece(jic, std::integral_constant<int, 7>{}, c, cn, src_off, wn);
-      piece(jic, std::integral_constant<int, 8>{}, c, cn, src_off, wn);
-#endif
-      SB();
+    if constexpr (ji == 0) ld_so = cn * 64;
+    h8 ah[3 * NREP], al[3 * NREP], bh[3], bl[3];
+    auto rdA = [&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
+      al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
     };
-    auto do_mfma = [&]() {
-      h8 ah[NG], al[NG], bh[3], bl[3];
-      auto rd_a = [&](int g) {
-        ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
-        al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
-      };
-      auto rd_b = [&](int dy) {
-        bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
-        bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
-      };
-      SB();
-      rd_a(0);
-      rd_b(0);
-      SB();
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int dy = g / NREP, nr = g - dy * NREP;
-        if (g + 1 < NG) {
-          rd_a(g + 1);
-          if ((g + 1) % NREP == 0) rd_b((g + 1) / NREP);
-        }
-        SB();
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g], bh[dy], acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bl[dy], acc[ji][nr], 0, 0, 0);
-        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g], bh[dy], acc[ji][nr], 0, 0, 0);
-        SB();
-      }
+    auto rdB = [&](auto dc) {
+      constexpr int dy = decltype(dc)::value;
+      bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
+      bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
     };
-    // (ONE copy of the MFMA code, the staging code before or after it: the accumulators pass through the conditional blocks untouched)
-    if (!mfma_first) do_staging();
-    do_mfma();
-    if (mfma_first) do_staging();
+    auto dma = [&](auto ic) { dma_piece(decltype(ic)::value, src_off, wn); };
+    auto mfma = [&](auto gc, auto pc_) {
+      constexpr int g = decltype(gc)::value, part = decltype(pc_)::value;
+      constexpr int dy = g / NREP, nr = g - dy * NREP;
+      const h8 wa = part == 0 ? al[g] : ah[g];
+      const h8 xv = part == 1 ? bl[dy] : bh[dy];
+      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
+    };
+#define WX_STAGE_CASE(N_, J_, P_) if constexpr (NREP == N_ && ji == J_ && PRE == P_) { WX4_STAGE_##N_##_##J_##_##P_ }
+#define WX_STAGE_PRE(N_, J_) WX_STAGE_CASE(N_, J_, 0) WX_STAGE_CASE(N_, J_, 1) WX_STAGE_CASE(N_, J_, 2)
+    WX_STAGE_PRE(1, 0) WX_STAGE_PRE(1, 1) WX_STAGE_PRE(1, 2)
+    WX_STAGE_PRE(2, 0) WX_STAGE_PRE(2, 1) WX_STAGE_PRE(2, 2)
+    WX_STAGE_PRE(3, 0) WX_STAGE_PRE(3, 1) WX_STAGE_PRE(3, 2)
+#undef WX_STAGE_PRE
+#undef WX_STAGE_CASE
     // end of stage: this wave's DMA pieces have landed (they are older than the pixel loads of stage 0, which stay in flight), its
     // LDS writes are done; then the workgroup barrier
-#ifdef VIRNET_F16_TIMING
-    {  // wave 0 accounts its stage: work until the waits, the vmcnt drain, the barrier
-      const long long ta = (long long)__builtin_amdgcn_s_memtime();
-      if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPX) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const long long tb = (long long)__builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const long long tl = (long long)__builtin_amdgcn_s_memtime();
-      asm volatile("s_barrier" ::: "memory");
-      const long long tc = (long long)__builtin_amdgcn_s_memtime();
-      wx_t[ji * 4 + 0] += ta - wx_tl; wx_t[ji * 4 + 1] += tb - ta; wx_t[ji * 4 + 2] += tl - tb; wx_t[ji * 4 + 3] += tc - tl;
-      wx_tl = tc;
-    }
-#else
-#if defined(WX_PROBE_NO_LOADS)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
     if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-#endif
   };
   for (int c = 0; c < nch; ++c) {
-    stage(c, I0{});
-    stage(c, I1{});
-    stage(c, I2{});
+    stage(c, WX_I(0));
+    stage(c, WX_I(1));
+    stage(c, WX_I(2));
   }
   TSTAMP(2);
-#ifdef VIRNET_F16_TIMING
-  if (a.tlog && (tid & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) a.tlog[(size_t)a.ntiles * ncb * 16 + ((size_t)blockIdx.x * 8 + wave) * 16 + i] = wx_t[i];
-  }
-#endif
 
   // ---- epilogue.  Per slab: wave (jt, rb) writes three blocks of [column = (row, x-tile)][32 channels] records
   //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
