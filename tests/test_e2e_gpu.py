@@ -149,7 +149,7 @@ def test_metric_shape_properties_256(manifest):
                 os.environ["VIRNET_CONV_FORM"] = old
 
 
-@pytest.mark.parametrize("form", ["f16x3", "wino"])
+@pytest.mark.parametrize("form", ["wx4", "f16x3", "wino"])
 def test_denoise_vs_oracle_256_pair(manifest, monkeypatch, form):
     """The metric's image size against the CPU oracle at a batch it finishes in seconds: [2,3,256,256]."""
     monkeypatch.setenv("VIRNET_CONV_FORM", form)

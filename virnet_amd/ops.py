@@ -92,7 +92,7 @@ def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct
 #                            GEMMs with bf16-rounded operands, one product per MAC; every other layer as f16x3
 # (older spelling, honoured when VIRNET_CONV_FORM is unset: VIRNET_WINOGRAD=0 -> direct, VIRNET_WINOGRAD=1 -> wino)
 WINO_MIN_CHANNELS = 32
-DEFAULT_CONV_FORM = "f16x3"
+DEFAULT_CONV_FORM = "wx4"
 
 
 def conv_form() -> str:
@@ -112,11 +112,13 @@ def _f16_family() -> bool:
 
 def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     """The Winograd-along-x kernel works on 16 x 32 pixel tiles x 96 channels, one workgroup per CU: worth it when the image fills its
-    tiles reasonably and the launch gives the chip's 256 CUs work (VIRNET_WX4_MIN_WG overrides the workgroup floor; tests use 0)."""
+    tiles reasonably.  The rule looks at ONE image's shape only (never at the batch size): a network's result for an image must not
+    depend on what else is in the batch (tests/test_e2e_gpu.py holds that bit for bit)."""
+    if cout < int(os.environ.get("VIRNET_WX4_MIN_COUT", "96")):          # (64 channels: two-slab workgroups re-stage the pixels for 18 MFMAs per stage; measured level with conv_f16)
+        return False
     th, tw = (h + 15) // 16, (w + 31) // 32
-    wgs = n * th * tw * ((cout + 95) // 96)
     fill = (h * w) / float(th * 16 * tw * 32)
-    return wgs >= int(os.environ.get("VIRNET_WX4_MIN_WG", "192")) and fill >= float(os.environ.get("VIRNET_WX4_MIN_FILL", "0.6"))
+    return th * tw >= int(os.environ.get("VIRNET_WX4_MIN_TILES", "4")) and fill >= float(os.environ.get("VIRNET_WX4_MIN_FILL", "0.6"))
 
 
 def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
