@@ -22,8 +22,8 @@ because the compiler's wait for a pixel load becomes vmcnt(0) once a DMA piece i
 Usage: python tools/gen_wx4_sched.py > virnet_amd/csrc/conv_f16_wx4_sched.inc      (knobs: CAP, LDS_LAT below)"""
 import sys
 
-CAP = 6        # issue units per slot (an MFMA hides about five single-issue instructions)
-LDS_LAT = 4    # slots between a fragment read and the MFMA that consumes it
+CAP = 5        # issue units per slot (an MFMA hides about five single-issue instructions)
+LDS_LAT = 3    # slots between a fragment read and the MFMA that consumes it
 HEAD_CAP = 14  # slot 0 sits behind the barrier, in front of the first MFMA which waits for its fragments anyway
 
 
@@ -183,6 +183,8 @@ def emit(nrep, ji, pre, out):
         line = "  SB(); " + " ".join(o.code for o in here) + " SB();"
         if s < nm:
             line += " mfma(%s, %s);" % (I(s // 3), I(s % 3))
+            if s % 3 == 2:
+                line += " WX_TS(%d);" % (s // 3)          # (timing builds: s_memtime stamp behind every MFMA group)
         out.append(line + " \\")
     out.append("  /* issue units per slot: %s */" % " ".join(str(x) for x in load))
     out.append("")

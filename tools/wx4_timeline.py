@@ -34,7 +34,7 @@ def main():
     ntiles = n * ((h + 15) // 16) * ((w + 31) // 32)
     ncb = (c + 95) // 96
     nwg = ntiles * ncb
-    log = torch.zeros(nwg * 16 + (nwg + 64) * 8 * 16 + 4096, dtype=torch.int64, device="cuda")
+    log = torch.zeros(nwg * 8 + (nwg + 64) * 8 * 32 + 4096, dtype=torch.int64, device="cuda")
     for _ in range(3):
         ops.conv_mfma(x, pw, **kw)
     torch.cuda.synchronize()
@@ -43,20 +43,19 @@ def main():
     torch.cuda.synchronize()
     lib.virnet_debug_timing_buffer(None)
     t = log.cpu().numpy()
-    st = t[:nwg * 8 + 64].reshape(-1, 8)
+    st = t[:nwg * 8].reshape(-1, 8)
     st = st[st[:, 0] != 0]
     pro, kl, ep = st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2]
     nst = (c // 16)
     print(f"{len(st)} workgroups; per workgroup (median cycles): prologue {np.median(pro):.0f}, K loop {np.median(kl):.0f} "
           f"({np.median(kl) / (3 * nst):.0f} per stage), epilogue {np.median(ep):.0f}")
-    acc = t[nwg * 16:nwg * 16 + nwg * 8 * 16].reshape(-1, 8, 16).astype(np.float64) / nst
+    acc = t[nwg * 8:nwg * 8 + nwg * 8 * 32].reshape(-1, 8, 32).astype(np.float64) / nst
     acc = acc[acc[:, 0, 0] != 0]
-    for wv in range(8):
-        line = []
+    print("cycles per MFMA group (3 MFMAs + the slots in front of them), g = 0..8, then tail + waits + barrier; median over workgroups")
+    for wv in (0, 4, 1, 5):
         for ji in range(3):
-            wk, vm, lg, br = (np.median(acc[:, wv, ji * 4 + k]) for k in range(4))
-            line.append(f"ji={ji}: work {wk:5.0f} vm {vm:4.0f} lgkm {lg:4.0f} bar {br:5.0f}")
-        print(f"  wave {wv}: " + "  |  ".join(line))
+            v = [np.median(acc[:, wv, ji * 10 + g]) for g in range(10)]
+            print(f"  wave {wv} stage {ji}: " + " ".join(f"{x:5.0f}" for x in v[:9]) + f"  | {v[9]:5.0f}   sum {sum(v):6.0f}")
 
 
 if __name__ == "__main__":

@@ -359,6 +359,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // The last chunk re-reads itself and rewrites its own dead planes: no branch in the stage code.  The end-of-stage wait of stage 0
   // leaves the pixel loads in flight: s_waitcnt vmcnt(pixel loads) covers the DMA pieces, which are issued before them.
   constexpr int NPX = 12 + (PRE == 2 ? 4 : 0);      // VMEM instructions of one chunk's pixel (+ SFT vector) loads
+#ifdef VIRNET_F16_TIMING
+  long long wx_tg[3][10] = {};
+#endif
   auto stage = [&](int c, auto jic) {
     constexpr int ji = decltype(jic)::value;
     const int s = c * 3 + ji;
@@ -388,6 +391,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       const h8 xv = part == 1 ? bl[dy] : bh[dy];
       acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
     };
+#ifdef VIRNET_F16_TIMING
+    long long wx_tprev = (long long)__builtin_amdgcn_s_memtime();
+#define WX_TS(g) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if ((g) < 9) wx_tg[ji][(g)] += t_ - wx_tprev; wx_tprev = t_; } while (0)
+#else
+#define WX_TS(g) do { } while (0)
+#endif
 #define WX_STAGE_CASE(N_, J_, P_) if constexpr (NREP == N_ && ji == J_ && PRE == P_) { WX4_STAGE_##N_##_##J_##_##P_ }
 #define WX_STAGE_PRE(N_, J_) WX_STAGE_CASE(N_, J_, 0) WX_STAGE_CASE(N_, J_, 1) WX_STAGE_CASE(N_, J_, 2)
     WX_STAGE_PRE(1, 0) WX_STAGE_PRE(1, 1) WX_STAGE_PRE(1, 2)
@@ -399,6 +408,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     // LDS writes are done; then the workgroup barrier
     if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef VIRNET_F16_TIMING
+    wx_tg[ji][9] += (long long)__builtin_amdgcn_s_memtime() - wx_tprev;       // tail slot + waits + barrier
+#endif
+#undef WX_TS
   };
   for (int c = 0; c < nch; ++c) {
     stage(c, WX_I(0));
@@ -406,6 +419,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     stage(c, WX_I(2));
   }
   TSTAMP(2);
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && (tid & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 10; ++g) a.tlog[(size_t)a.ntiles * ncb * 8 + ((size_t)blockIdx.x * 8 + wave) * 32 + j * 10 + g] = wx_tg[j][g];
+  }
+#endif
 
   // ---- epilogue.  Per slab: wave (jt, rb) writes three blocks of [column = (row, x-tile)][32 channels] records
   //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
