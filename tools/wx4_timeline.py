@@ -49,6 +49,9 @@ def main():
     nst = (c // 16)
     print(f"{len(st)} workgroups; per workgroup (median cycles): prologue {np.median(pro):.0f}, K loop {np.median(kl):.0f} "
           f"({np.median(kl) / (3 * nst):.0f} per stage), epilogue {np.median(ep):.0f}")
+    if st[:, 6].any():
+        print(f"epilogue split (median cycles after the K loop): first exchange written + barrier {np.median(st[:, 6] - st[:, 2]):.0f}, "
+              f"slab 0 stored {np.median(st[:, 7] - st[:, 2]):.0f}, exit {np.median(ep):.0f}")
     acc = t[nwg * 8:nwg * 8 + nwg * 8 * 32].reshape(-1, 8, 32).astype(np.float64) / nst
     acc = acc[acc[:, 0, 0] != 0]
     print("cycles per MFMA group (3 MFMAs + the slots in front of them), g = 0..8, then tail + waits + barrier; median over workgroups")

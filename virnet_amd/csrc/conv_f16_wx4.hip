@@ -85,6 +85,9 @@ __device__ __forceinline__ float subhi(float v, unsigned hpk) {
   return r;
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. would wait for global loads in flight
+__device__ __forceinline__ void wx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct WxItem {
   unsigned voff;     // byte offset of the item's first input pixel (row, 4*xtile - 1) from the image base; may wrap (the load is masked)
   unsigned inb;      // bit b: pixel b lies inside the image
@@ -502,13 +505,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) op1[nr & 1][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
     };
-    xwrite(0);
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nbase + nr * 32 + cq * 4);
       bias4[nr] = *reinterpret_cast<const f32x4*>(bp + nbase + nr * 32 + cq * 4);
     }
     if (ONE) load_op1(0);
+    SB();
+    xwrite(0);
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
     unsigned yoff[NIT];
 #pragma unroll
@@ -516,7 +520,8 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       if (nr > 0) xwrite(nr);
-      __syncthreads();
+      wx_lds_barrier();
+      if (nr == 0) TSTAMP(6);
       if (ONE && nr + 1 < NREP) load_op1(nr + 1);
       f32x4 mv[NIT], rv[NIT];
       if (EPI == 3) {
@@ -530,12 +535,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       f32x4 tv[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) tv[it] = xread(it);
-#if defined(__HIP_DEVICE_COMPILE__)
-      if (ONE && nr + 1 < NREP) {                    // keep the next slab's requests above this slab's stores
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(op1[(nr + 1) & 1][it]));
-      }
-#endif
+      SB();                                          // (the next slab's operand requests stay above this slab's stores)
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         f32x4 v = tv[it] * inv4[nr] + b4;
@@ -545,7 +545,8 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
         // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
       }
-      if (nr + 1 < NREP) __syncthreads();
+      if (nr == 0) TSTAMP(7);
+      if (nr + 1 < NREP) wx_lds_barrier();
     }
   } else {
     // generic form (two stored tensors and / or SFT on the output): optional operands by runtime pointer
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       xwrite(nr);
-      __syncthreads();
+      wx_lds_barrier();
       const int co = nbase + nr * 32 + cq * 4;
       const f32x4 inv4 = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
       const f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
           if (yact) *reinterpret_cast<f32x4*>(yact + eoff[it] + nr * 32) = lrelu4(v * mul4 + add4, a.slope);
         }
       }
-      if (nr + 1 < NREP) __syncthreads();
+      if (nr + 1 < NREP) wx_lds_barrier();
     }
   }
   TSTAMP(3);
@@ -631,10 +632,10 @@ __global__ void pack_wx4_kernel(const float* __restrict__ w, int kind, int cout,
   float m = 0.f;
   for (int i = threadIdx.x; i < ks * 18; i += blockDim.x) m = fmaxf(m, fabsf((float)uval(i / 18, (i % 18) % 3, (i % 18) / 3)));
   red[threadIdx.x] = m;
-  __syncthreads();
+  wx_lds_barrier();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-    __syncthreads();
+    wx_lds_barrier();
   }
   m = red[0];
   int e = 0;
