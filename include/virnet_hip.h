@@ -166,6 +166,13 @@ size_t virnet_wx4_weight_floats(int cin_pad, int n_pad);
 int virnet_pack_wx4_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
 int virnet_conv_wx4(const virnet_conv_desc* d, void* stream);
 
+/* Range guard of the split-fp16 kernels (virnet_conv_f16 incl. its stride-2 / transposed forms, virnet_conv_wx4).  An operand of magnitude
+ * >= 65520 (transformed magnitude for virnet_conv_wx4: up to 10x the activation) does not fit fp16: the product turns Inf / NaN, which is
+ * loud in a tensor but clamped away by the exp(clamp(.)) / tanh epilogues (VIRNet.py:43, KNet.py:56-58).  Register a zeroed device int per
+ * device (NULL = off); the kernels OR 1 into it when a staged operand leaves the range.  The host side (virnet_amd/engine.py) reads it at
+ * the end of a forward and re-runs the image in the fp32 Winograd form.  The reference's fp32 path has no such limit. */
+int virnet_set_range_flag(int* device_flag);
+
 /* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):
  * AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173), DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43),

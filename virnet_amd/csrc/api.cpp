@@ -1,5 +1,6 @@
 // api.cpp -- process-level pieces of the C ABI (version, error slot, device probe).
 #include "common.h"
+namespace virnet { int* range_flag_ptr(); }
 #include "../../include/virnet_hip.h"
 
 namespace virnet {
@@ -17,6 +18,14 @@ int set_error(const char* fmt, ...) {
   return 1;
 }
 
+static int* g_range_flag[64] = {nullptr};
+
+int* range_flag_ptr() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
+  return g_range_flag[dev];
+}
+
 }  // namespace virnet
 
 extern "C" int virnet_abi_version(void) { return VIRNET_ABI_VERSION; }
@@ -31,4 +40,13 @@ extern "C" int virnet_device_count(void) {
     return -1;
   }
   return n;
+}
+
+extern "C" int virnet_set_range_flag(int* device_flag) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return virnet::set_error("virnet_set_range_flag: hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev > 63) return virnet::set_error("virnet_set_range_flag: device %d out of range", dev);
+  virnet::g_range_flag[dev] = device_flag;
+  return 0;
 }

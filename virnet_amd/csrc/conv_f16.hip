@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   const float* const imul = in_sft ? a.in_mul + (size_t)img * a.Cin + (tid & 1) * 8 : nullptr;
   const float* const iadd = in_sft ? a.in_add + (size_t)img * a.Cin + (tid & 1) * 8 : nullptr;
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  float amax = 0.f;                                // range guard (conv_f16_common.h)
   auto stage_store = [&](char* xb, int chunk, int k, f32x4 r0, f32x4 r1) {
     if (in_sft) {
       const f32x4 m0 = *reinterpret_cast<const f32x4*>(imul + chunk * 16), m1 = *reinterpret_cast<const f32x4*>(imul + chunk * 16 + 4);
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       *reinterpret_cast<b8*>(xb + sdst[k]) = to_bf16x8(r0, r1);
     } else {
       h8 hi, lo;
+      range_note(amax, r0, r1);
       split8(r0, r1, hi, lo);
       *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
       *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   }
   if (c < nch) { group(c, I0{}, I0{}); group(c, I0{}, I1{}); group(c, I0{}, I2{}); }
   TSTAMP(2);
+  range_report(a.range_flag, amax);
 
   // ---- epilogue
   if constexpr (EPI == 5) {
@@ -579,6 +582,7 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
     t.x = d->x; t.inv_scale = d->wpack; t.wimg = reinterpret_cast<const char*>(d->wpack + d->n_pad);
     t.bias = d->bias; t.res = d->res; t.y_raw = d->y_raw; t.y_act = d->y_act;
     t.N = d->n; t.H = d->h; t.W = d->w; t.cout = d->cout; t.in_act = d->in_act; t.in_slope = d->in_slope; t.slope = d->slope;
+    t.range_flag = virnet::range_flag_ptr();
     return virnet::launch_f16_convt(t, d->cin_pad, static_cast<hipStream_t>(stream));
   }
   VIRNET_REQUIRE(d->ks == 3 && ((d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW)) || (d->stride == 2 && d->epi == VIRNET_EPI_NHWC)),
@@ -613,6 +617,7 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
   k.tlog = g_tlog;
 #endif
   hipStream_t st = static_cast<hipStream_t>(stream);
+  k.range_flag = bf ? nullptr : virnet::range_flag_ptr();
   k.OH = d->h; k.OW = d->w;
   if (d->stride == 2) {                                         // DownBlock.downsampler (AttResUNet.py:67): conv_f16_s2.hip
     VIRNET_REQUIRE(d->h % 2 == 0 && d->w % 2 == 0, "virnet_conv_f16: stride-2 input %dx%d must be even", d->h, d->w);

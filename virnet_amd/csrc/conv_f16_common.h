@@ -43,11 +43,22 @@ struct FArgs {
   int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
   float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
   long long* tlog;
+  int* range_flag;         // sticky device flag (virnet_set_range_flag) set when a staged operand leaves fp16's range, or NULL
 };
 
 __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
   const f32x4 t = u * s;
   return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};
+}
+
+// Range guard of the split-fp16 kernels: an operand of magnitude >= 65520 rounds to an fp16 infinity and the result turns Inf / NaN --
+// loud in the tensors, but clamped away by exp(clamp(.)) / tanh epilogues (VIRNet.py:43, KNet.py:56-58).  Every kernel keeps the largest
+// staged magnitude per thread and raises the sticky flag once, after its K loop; the host side re-runs the forward in the fp32 form.
+__device__ __forceinline__ void range_note(float& amax, const f32x4& a, const f32x4& b) {
+  amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fmaxf(fabsf(a.z), fabsf(a.w)), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+}
+__device__ __forceinline__ void range_report(int* flag, float amax) {
+  if (flag != nullptr && amax >= 65520.f) atomicOr(flag, 1);
 }
 
 // v = hi + lo in fp16 (round to nearest even both times)
@@ -69,6 +80,9 @@ __device__ __forceinline__ b8 to_bf16x8(const f32x4& a, const f32x4& b) {
   for (int e = 0; e < 8; ++e) r[e] = (__bf16)v[e];
   return r;
 }
+
+// the flag registered for the current device (api.cpp), or NULL
+int* range_flag_ptr();
 
 // stride-2 form (conv_f16_s2.hip): `k` filled as for the stride-1 launch, H/W = INPUT size, OH/OW = output size; nb = 32-channel slabs
 int launch_f16_s2(FArgs k, int nb, hipStream_t st);

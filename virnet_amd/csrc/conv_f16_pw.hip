@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     sdst[k] = kc * KC + pl * 32 + ((h ^ ((pl >> 3) & 1)) << 4);
   }
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  float amax = 0.f;                                // range guard (conv_f16_common.h)
   auto stage_store = [&](char* xb, int k, f32x4 r0, f32x4 r1) {
     r0 = lrelu4(r0, in_slope_eff);
     r1 = lrelu4(r1, in_slope_eff);
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     r0 = sinb[k] ? r0 : z;
     r1 = sinb[k] ? r1 : z;
     h8 hi, lo;
+    range_note(amax, r0, r1);
     split8(r0, r1, hi, lo);
     *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
     *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
   for (; s + 1 < nst; s += 2) { stage_fn(s, I0{}); stage_fn(s + 1, I1{}); }
   if (s < nst) stage_fn(s, I0{});
 
+  range_report(a.range_flag, amax);
   // ---- epilogue: GEMM row slab -> phase (a, b) and channel offset; pixel -> (image, y, x) -> output (2y+a, 2x+b)
   const int C = a.cout;                                   // channels of the up-sampled tensor
   const int W2 = 2 * a.W;

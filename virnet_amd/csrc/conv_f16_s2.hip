@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
     sdst[k] = p * 32 + ((h ^ ((p >> 3) & 1)) << 4);
   }
   const float in_slope_eff = a.in_act ? a.in_slope : 1.f;
+  float amax = 0.f;                                // range guard (conv_f16_common.h)
   auto stage_store = [&](char* xb, int k, f32x4 r0, f32x4 r1) {
     r0 = lrelu4(r0, in_slope_eff);
     r1 = lrelu4(r1, in_slope_eff);
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
     r0 = sinb[k] ? r0 : z;
     r1 = sinb[k] ? r1 : z;
     h8 hi, lo;
+    range_note(amax, r0, r1);
     split8(r0, r1, hi, lo);
     *reinterpret_cast<h8*>(xb + sdst[k]) = hi;
     *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
   }
   if (c < nch) { group(c, I0{}, I0{}); group(c, I0{}, I1{}); group(c, I0{}, I2{}); }
 
+  range_report(a.range_flag, amax);
   // ---- epilogue: per-wave LDS turn-around of each 32-channel slab, every load before the first store, branch-free buffer stores
   const int nbase = (a.slab_base + cb * SLABS + sg * NREP) * 32;
   const int C = a.cout;

@@ -257,8 +257,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     else if constexpr (J == 3) pc[X].v = pc[X].a + 2.f * pc[X].b;
     else pc[X].v = pc[X].a - 2.f * pc[X].b;
   };
+  float amax = 0.f;                                // range guard (conv_f16_common.h): largest transformed magnitude this thread staged
   auto pHi = [&](auto xc) {
     constexpr int X = decltype(xc)::value;
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(pc[X].v.x), fabsf(pc[X].v.y))), fmaxf(fabsf(pc[X].v.z), fabsf(pc[X].v.w)));
     pc[X].h0 = cvtpk(pc[X].v.x, pc[X].v.y);
     pc[X].h1 = cvtpk(pc[X].v.z, pc[X].v.w);
   };
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     hw = fmaf(hc[JW][5], dh[5], fmaf(hc[JW][4], dh[4], hc[JW][2] * dh[2]));
   };
   auto hV = [&]() { hv += hw; };
-  auto hHi = [&]() { hhi = (_Float16)hv; };
+  auto hHi = [&]() { amax = fmaxf(amax, fabsf(hv)); hhi = (_Float16)hv; };
   auto hSub = [&]() { hw = hv - (float)hhi; };
   auto hLo = [&]() { hlo = (_Float16)hw; };
   auto hSt = [&](auto jwc) {
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     stage(c, WX_I(2));
   }
   TSTAMP(2);
+  range_report(a.range_flag, amax);
 #ifdef VIRNET_F16_TIMING
   if (a.tlog && (tid & 63) == 0) {
 #pragma unroll
@@ -699,6 +702,7 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
   k.tlog = virnet_f16_tlog();
 #endif
   hipStream_t st = static_cast<hipStream_t>(stream);
+  k.range_flag = virnet::range_flag_ptr();
   const int nb = d->n_pad / 32;
   const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
   const int pre = d->in_mul ? 2 : (d->in_act != 0);

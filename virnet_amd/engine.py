@@ -170,10 +170,36 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
 # ----------------------------------------------------------------------------------------------------------------
 # boundary forwards (reference networks/VIRNet.py:42-46 and :80-97)
 # ----------------------------------------------------------------------------------------------------------------
+def _range_guarded(run, x: Tensor):
+    """Run a forward in the default (split-fp16) forms; when a kernel reports an operand outside fp16's range (virnet_set_range_flag)
+    run it again with the fp32 kernels (VIRNET_CONV_FORM=wino: Winograd / direct fp32 MFMA, no range limit) and return that result.
+    The check reads one int from the device, i.e. it waits for the forward; it is skipped while a hipGraph is being captured, for
+    the fp32 forms and with VIRNET_RANGE_GUARD=0."""
+    import os
+    import warnings
+    guarded = ops._f16_family() and ops.range_guard_enabled() and not torch.cuda.is_current_stream_capturing()
+    if guarded:
+        ops.range_flag(x.device)
+    out = run()
+    if guarded and ops.range_overflowed(x.device):
+        warnings.warn("VIRNet HIP path: an activation left fp16's range in a split-fp16 convolution (|x| >= 65504, or >= ~6.5e3 in the "
+                      "Winograd form); the forward was repeated with the fp32 kernels", RuntimeWarning, stacklevel=3)
+        old = os.environ.get("VIRNET_CONV_FORM")
+        os.environ["VIRNET_CONV_FORM"] = "wino"
+        try:
+            out = run()
+        finally:
+            if old is None:
+                os.environ.pop("VIRNET_CONV_FORM", None)
+            else:
+                os.environ["VIRNET_CONV_FORM"] = old
+    return out
+
+
 def denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
     x = _prep(x, net.SNet.in_channels)
     with torch.cuda.device(x.device):       # launches go to x's device even when it is not the process's current one
-        return _denoise_forward(net, x)
+        return _range_guarded(lambda: _denoise_forward(net, x), x)
 
 
 def _denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
@@ -192,7 +218,7 @@ def _denoise_forward(net, x: Tensor) -> Tuple[Tensor, Tensor]:
 def sisr_forward(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     x = _prep(x, net.SNet.in_channels)
     with torch.cuda.device(x.device):
-        return _sisr_forward(net, x, sf)
+        return _range_guarded(lambda: _sisr_forward(net, x, sf), x)
 
 
 def _sisr_forward(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:

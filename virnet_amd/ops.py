@@ -143,6 +143,41 @@ def _wino_enabled() -> bool:
     return conv_form() == "wino"
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# range guard of the split-fp16 forms (include/virnet_hip.h: virnet_set_range_flag)
+# ----------------------------------------------------------------------------------------------------------------------
+_RANGE_FLAGS: dict = {}
+
+
+def range_guard_enabled() -> bool:
+    return os.environ.get("VIRNET_RANGE_GUARD", "1") != "0"
+
+
+def range_flag(device: torch.device) -> Optional[Tensor]:
+    """The sticky int32 flag of ``device`` (created zeroed and registered with the library on first use); None when the guard is off."""
+    if not range_guard_enabled():
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    flag = _RANGE_FLAGS.get(idx)
+    if flag is None:
+        flag = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        with torch.cuda.device(idx):
+            nat.check(nat.load().virnet_set_range_flag(nat.ptr(flag)), "set_range_flag")
+        _RANGE_FLAGS[idx] = flag
+    return flag
+
+
+def range_overflowed(device: torch.device, *, reset: bool = True) -> bool:
+    """True when a split-fp16 kernel staged an operand outside fp16's range since the last reset (one device -> host read: it waits for
+    the launches enqueued so far)."""
+    flag = range_flag(device)
+    if flag is None or not bool(flag.item()):
+        return False
+    if reset:
+        flag.zero_()
+    return True
+
+
 def pack_f16_weight(weight: Tensor, *, dgrad: bool = False, bf16: bool = False) -> Tensor:
     """Split-fp16 image (+ per-row inverse scales) of an OIHW 3x3 weight for virnet_conv_f16 (``dgrad``: of the input-gradient GEMM);
     ``bf16``: the bf16-operand image for virnet_conv_bf16 instead (same size and layout)."""
