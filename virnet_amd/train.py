@@ -232,6 +232,18 @@ class DenoiseFunction(torch.autograd.Function):
         dev = (dmu if dmu is not None else dsigma).device
         reducer = getattr(ctx.net, "_grad_reducer", None)
         with torch.no_grad(), torch.cuda.device(dev):
+            # The backward is linear in (dmu, dsigma) and its GEMMs split their operands into fp16 pairs, whose exact range is
+            # 6e-5 .. 65504: the incoming gradients are scaled by a power of two (exact) so that their largest entry sits in [0.5, 1),
+            # and the parameter gradients are scaled back at the end -- the result does not depend on how the caller scaled its loss
+            # (a mean-reduced MSE hands over ~6e-8 per entry, a sum-reduced loss or a GradScaler 1e4 and more).  No host sync.
+            amax = torch.zeros((), dtype=torch.float32, device=dev)
+            for g in (dmu, dsigma):
+                if g is not None:
+                    amax = torch.maximum(amax, g.detach().abs().amax())
+            scale = torch.exp2(torch.clamp(-torch.floor(torch.log2(amax.clamp_min(1e-37))) - 1.0, -100.0, 100.0))
+            scale = torch.where(amax > 0, scale, torch.ones_like(scale))
+            dmu = None if dmu is None else dmu * scale
+            dsigma = None if dsigma is None else dsigma * scale
             if reducer is not None:
                 reducer.start()
             grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma, reducer=reducer)
@@ -240,6 +252,9 @@ class DenoiseFunction(torch.autograd.Function):
                 torch.cuda.current_stream(dev).wait_stream(side)      # gradients produced on the side stream are consumed after this
             if reducer is not None:
                 grads = reducer.finish()                  # averaged over the ranks (copies of the flat buckets' slices)
+            outs = [g for g in grads.values() if g is not None]
+            if outs:
+                torch._foreach_mul_(outs, 1.0 / scale)    # (a power of two: exact)
         ctx.tape = None
         return (None, None) + tuple(grads.get(p) if p.requires_grad else None for p in ctx.params)
 
