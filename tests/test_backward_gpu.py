@@ -378,3 +378,68 @@ def test_training_step_bf16_operand_variant(monkeypatch):
         worst = max(worst, float((g - gr).abs().median()) / scale)
         assert float((g - gr).abs().median()) / scale <= 5e-2, name
     assert worst > 1e-5
+
+
+def test_train_step_config4_as_written_bf16_full_size(monkeypatch):
+    """BASELINE configs[4] AS WRITTEN: [32,3,128,128], bf16 operands (VIRNET_CONV_FORM=bf16: the large-grid instantiations of the bf16
+    forward / input-gradient kernels and conv_wgrad_f16_kernel<..., BF=1> at their real sizes).  Size-independent properties: the forward
+    is batch independent bit for bit; every parameter gradient of the batch step equals the mean of the single-image steps (checked on
+    a subset of the images against the matching sub-batch: the bf16 rounding is per operand, so it commutes with batching); everything
+    is finite; the fp32-class step and the bf16 step agree to the bf16 operand error (5 % of each gradient's scale in the median
+    element); and three Adam steps on the batch descend."""
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    cfg = dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input")
+    net = VIRAttResUNet(**cfg)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    n = 32
+    gt = synth_images(n, 3, 128, 128, seed=1).cuda()
+    sig_gt = (0.02 + 0.25 * synth_images(n, 1, 128, 128, seed=2).cuda()) ** 2
+    noisy = gt + (synth_images(n, 3, 128, 128, seed=3).cuda() - 0.5) * 0.4
+    params = dict(net.named_parameters())
+
+    def step(sl):
+        for p in params.values():
+            p.grad = None
+        mu, sigma = net(noisy[sl].contiguous())
+        loss = _elbo(mu, sigma, noisy[sl], gt[sl], sig_gt[sl], eps2=1e-2)
+        loss.backward()
+        return float(loss), mu.detach(), {k: p.grad.double().clone() for k, p in params.items()}
+
+    monkeypatch.setenv("VIRNET_CONV_FORM", "wx4")
+    _, mu_f32, g_f32 = step(slice(0, n))
+    monkeypatch.setenv("VIRNET_CONV_FORM", "bf16")
+    loss_b, mu_b, g_b = step(slice(0, n))
+    assert all(bool(torch.isfinite(v).all()) for v in g_b.values()) and bool(torch.isfinite(mu_b).all())
+    assert 1e-5 < float((mu_b - mu_f32).abs().max()) < 0.1                   # really the reduced-precision kernels, and bounded
+    for k in g_b:
+        scale = max(float(g_f32[k].abs().max()), 1e-12)
+        assert float((g_b[k] - g_f32[k]).abs().median()) / scale <= 5e-2, k
+    # batch-mean property on the first four images (the sub-batch step vs the mean of its single-image steps), forward bit for bit
+    _, mu4, g4 = step(slice(0, 4))
+    assert torch.equal(mu4, mu_b[:4])
+    acc = {k: torch.zeros_like(v) for k, v in g4.items()}
+    for i in range(4):
+        _, mi, gi = step(slice(i, i + 1))
+        assert torch.equal(mi[0], mu_b[i])
+        for k in acc:
+            acc[k] += gi[k]
+    for k in acc:
+        ref = acc[k] / 4
+        scale = max(float(ref.abs().max()), 1e-12)
+        assert float((g4[k] - ref).abs().max()) / scale <= 1e-4, (k, float((g4[k] - ref).abs().max()) / scale)
+    # the step descends (train_denoising_syn.py:176-184: clip + Adam)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        mu, sigma = net(noisy)
+        loss = _elbo(mu, sigma, noisy, gt, sig_gt, eps2=1e-2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([p for n_, p in net.named_parameters() if "rnet" in n_.lower()], 1e3)
+        torch.nn.utils.clip_grad_norm_([p for n_, p in net.named_parameters() if "snet" in n_.lower()], 1e2)
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0], losses

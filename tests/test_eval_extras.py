@@ -45,7 +45,7 @@ def test_sisr_table_plumbing_cpu():
     def forward(lr, sf):
         return np.repeat(np.repeat(lr, sf, axis=0), sf, axis=1)
     rows = se.sisr_table(forward, [os.path.join(GOLDEN, "set5") + ":bmp"], 4, kernels=se.test_kernels(4)[:2], with_ssim=False)
-    assert [r["kernel"] for r in rows] == [1, 2] and all(r["images"] == 1 for r in rows)
+    assert [r["kernel"] for r in rows] == [1, 2] and all(r["images"] == 5 for r in rows)
     assert all(15.0 < r["psnr_y"] < 30.0 for r in rows) and rows[0]["psnr_y"] != rows[1]["psnr_y"]
     assert se.sisr_table(forward, [os.path.join(GOLDEN, "nowhere") + ":bmp"], 4) == []
 

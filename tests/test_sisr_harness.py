@@ -58,6 +58,42 @@ def test_degrade_rejects_bad_input():
 
 
 @pytest.mark.gpu
+def test_set5_x4_all_images_psnr_parity():
+    """BASELINE.json: 'PSNR within 0.01 dB on ... Set5' -- all five Set5 images (modcropped, 228x344 ... 512x512), x4, the first and
+    the sixth test kernel, nlevel 2.55, bicubic: per-image Y-PSNR of the HIP forward vs the CPU oracle and their mean over the set."""
+    from oracle import cpu_ref
+    from virnet_amd.networks.VIRNet import VIRAttResUNetSR
+    from virnet_amd.utils.synth import synth_state_dict
+    cfg = dict(im_chn=3, sigma_chn=1, kernel_chn=3, n_feat=[96, 160, 224], dep_S=5, dep_K=8, noise_cond=True, kernel_cond=True,
+               n_resblocks=2, extra_mode="Both", noise_avg=True)                   # scripts/sisr_virnet_syn.py:53-63
+    net = VIRAttResUNetSR(**cfg)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5)
+    net.load_state_dict(sd)
+    net = net.cuda()
+    kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn", "kernel_chn")}
+    names = sorted(n for n in os.listdir(os.path.join(GOLDEN, "set5")) if n.endswith(".bmp"))
+    assert len(names) == 5
+    sf = 4
+    to_u8 = lambda t: veval.img_as_ubyte(t.clamp(0.0, 1.0).squeeze(0).numpy().transpose(1, 2, 0))
+    for kidx in (0, 5):
+        pa_all, pb_all = [], []
+        for name in names:
+            gt = se.modcrop(veval.imread_rgb_uint8(os.path.join(GOLDEN, "set5", name)), sf)
+            lr = se.degrade(veval.img_as_float32(gt), se.test_kernels(sf)[kidx], sf, nlevel=2.55, downsampler="bicubic")
+            x = torch.from_numpy(lr.transpose(2, 0, 1)[None].copy())
+            with torch.no_grad():
+                mu_ref, _, _ = cpu_ref.virnet_sisr(sd, x, sf, **kw)
+                mu, _, _ = net(x.cuda(), sf)
+            assert (mu.cpu() - mu_ref).abs().max().item() <= 1e-3, name
+            a, b = to_u8(mu.cpu()), to_u8(mu_ref)
+            pa, pb = veval.calculate_psnr_y(a, gt, border=sf ** 2), veval.calculate_psnr_y(b, gt, border=sf ** 2)
+            assert abs(pa - pb) <= 0.01, (name, kidx, pa, pb)
+            pa_all.append(pa)
+            pb_all.append(pb)
+        assert abs(float(np.mean(pa_all)) - float(np.mean(pb_all))) <= 0.01
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sf,kidx", [(4, 0), (4, 5), (2, 3)])
 def test_set5_psnr_parity_hip_vs_oracle(sf, kidx):
     from oracle import cpu_ref
