@@ -54,8 +54,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0          # same guide: BF16/F16 MFMA ~2.5 PFLOP/s 
 FORMS = {"wx4": (1.5, F16_MFMA_PEAK_TFLOPS, "Winograd F(4,3) along x (18 instead of 36 k-steps per 4 output pixels) with split-fp16 position products: 1.5 executed "
                                             "FLOP per algorithmic FLOP on v_mfma_f32_32x32x16_f16, fp32 accumulation; layers / shapes it does not cover run as f16x3"),
          "f16x3": (3.0, F16_MFMA_PEAK_TFLOPS, "split-fp16 operands: 3 products per MAC on v_mfma_f32_32x32x16_f16, fp32 accumulation"),
-         "bf16": (1.0, F16_MFMA_PEAK_TFLOPS, "bf16-rounded operands: 1 product per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulation (C->C 3x3 convs "
-                                            "forward + input gradients; weight gradients fp32 MFMA, other layers split-fp16)"),
+         "bf16": (1.0, F16_MFMA_PEAK_TFLOPS, "bf16-rounded operands: 1 product per MAC on v_mfma_f32_32x32x16_bf16, fp32 accumulation (C->C 3x3 convs: "
+                                            "forward, input gradients AND weight gradients; thin layers, strided / transposed convs split-fp16 or fp32)"),
          "wino": (16.0 / 36.0, FP32_MFMA_PEAK_TFLOPS, "Winograd F(2x2,3x3), fp32: 16/36 of the algorithmic MACs on v_mfma_f32_32x32x2_f32"),
          "direct": (1.0, FP32_MFMA_PEAK_TFLOPS, "direct implicit GEMM, fp32 on v_mfma_f32_32x32x2_f32")}
 KFLOP_PER_PIXEL = 4988.736             # conv FLOPs (2*MAC) of the denoise-syn forward per padded pixel
@@ -135,8 +135,8 @@ def main():
                          "train_sisr = the SISR step (train_SISR.py:207-224) on configs[3]'s shape: forward x4 + elbo_sisr + backward")
     ap.add_argument("--optimizer", action="store_true", help="train task: include grad clipping + Adam step in the timed step")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="train task: bf16 = BASELINE configs[4]'s variant -- the C->C 3x3 convs of forward and backward (input gradients) run "
-                         "with bf16-rounded operands, one product per MAC, fp32 accumulation; weight gradients and all other layers stay fp32-class")
+                    help="train task: bf16 = BASELINE configs[4]'s variant -- the C->C 3x3 convs of forward and backward (input AND weight "
+                         "gradients) run with bf16-rounded operands, one product per MAC, fp32 accumulation; all other layers stay fp32-class")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -202,10 +202,14 @@ def main():
         opt = torch.optim.Adam(net.parameters(), lr=2e-4) if args.optimizer else None
         groups = {key: [p for nm, p in net.named_parameters() if key in nm.lower()] for key in ("rnet", "snet", "knet")}
 
+        # N > 1: data-parallel training as train_SISR.py (DDP): the per-layer autograd nodes of the SISR step fire torch DDP's hooks
+        # layer by layer, so the bucketed RCCL all-reduces overlap with the rest of the backward
+        model_sr = torch.nn.parallel.DistributedDataParallel(net, device_ids=[dev.index]) if world > 1 else net
+
         def fwd(t):
             for p in net.parameters():
                 p.grad = None
-            mu_, kinfo_, sig_ = net(t, 4)
+            mu_, kinfo_, sig_ = model_sr(t, 4)
             loss = elbo_sisr(mu=mu_, sigma_est=sig_, kinfo_est=kinfo_, im_hr=im_hr, im_lr=t, sigma_prior=nlevel, alpha0=alpha0, kinfo_gt=kinfo_gt,
                              kappa0=kappa0, r2=1e-4, eps2=1e-5, sf=4, k_size=21, penalty_K=[0.02, 2], shift=False, downsampler="Bicubic")[0]
             loss.backward()
@@ -333,7 +337,7 @@ def main():
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
                        "arithmetic": "fp32 tensors and accumulation; C->C 3x3 convs: " + FORMS[ops.conv_form()][2],
                        "parallelism": (f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), "
-                                       + ("gradient all-reduce per step (fp32, 8 MB buckets, started inside the backward)" if (training and not train_sisr and world > 1)
+                                       + ("gradient all-reduce per step (fp32 buckets, started inside the backward)" if (training and world > 1)
                                           else "no per-image collective"))},
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},

@@ -102,6 +102,34 @@ def test_forward_tiled_on_the_hip_path(manifest):
 
 
 @pytest.mark.gpu
+def test_forward_tiled_sisr_keeps_the_conditioning_global():
+    """VIRAttResUNetSR pools SNet / KNet over the whole input: tiling the MODULE would give every tile its own sigma / kernel estimate
+    (visibly different from the untiled result); forward_tiled_sisr estimates both once and tiles only RNet -- the conditioning is the
+    full forward's bit for bit, a tile covering the image reproduces the module exactly, real tiling stays close to it and much closer
+    than the naive per-tile module call."""
+    from virnet_amd.networks import VIRAttResUNetSR
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    from virnet_amd.utils.tiling import forward_tiled_sisr
+    cfg = dict(im_chn=3, sigma_chn=1, kernel_chn=3, n_feat=[96, 160, 224], dep_S=5, dep_K=8, noise_cond=True, kernel_cond=True,
+               n_resblocks=2, extra_mode="Both", noise_avg=True)
+    net = VIRAttResUNetSR(**cfg)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5))
+    net = net.cuda().eval()
+    x = synth_images(1, 3, 96, 128).cuda()
+    x[:, :, :, 64:] *= 0.3                                  # two halves with different statistics: per-tile pooling would differ
+    with torch.no_grad():
+        mu, kinfo, sigma = net(x, 2)
+        mu1, k1, s1 = forward_tiled_sisr(net, x, 2, tile=256)
+        assert torch.equal(mu1, mu) and torch.equal(k1, kinfo) and torch.equal(s1, sigma)
+        mu_t, k_t, s_t = forward_tiled_sisr(net, x, 2, tile=64, overlap=16, batch=4)
+        assert torch.equal(k_t, kinfo) and torch.equal(s_t, sigma)
+        naive = forward_tiled(lambda t: net(t, 2)[0], x, tile=64, overlap=16, scale=2, batch=1)
+    err_t = float((mu_t - mu).abs().mean() / mu.abs().mean())
+    err_naive = float((naive - mu).abs().mean() / mu.abs().mean())
+    assert err_t < 0.05 and err_t < 0.5 * err_naive, (err_t, err_naive)
+
+
+@pytest.mark.gpu
 def test_flip_ensemble_on_the_hip_path(manifest):
     """denoising_virnet_real_sidd.py:120-136 with the drop-in module: eight forwards on transformed inputs (two image orientations),
     HIP ensemble vs the same ensemble through the CPU oracle."""

@@ -58,6 +58,16 @@ def sigma2kernel(cov: Tensor, k_size: int = 21, sf: int = 3, shift: bool = False
 
 
 def _bicubic_matrix(n_in: int, sf: int, device, dtype) -> Tensor:
+    """Cached per (size, factor, device, dtype): the matrix is a constant of the training shape, and building it on the host + the
+    pageable host-to-device copy (a sync) used to sit inside every elbo_sisr call."""
+    return _bicubic_matrix_cached(int(n_in), int(sf), str(device), dtype)
+
+
+import functools  # noqa: E402
+
+
+@functools.lru_cache(maxsize=32)
+def _bicubic_matrix_cached(n_in: int, sf: int, device: str, dtype) -> Tensor:
     """[ceil(n_in/sf), n_in] weights of the antialiased cubic the reference vendors as ResizeRight (same construction as
     virnet_amd.sisr_eval._resample_axis0: stretched cubic, taps mirrored at the borders, rows normalised)."""
     from .sisr_eval import _cubic
@@ -77,7 +87,7 @@ def _bicubic_matrix(n_in: int, sf: int, device, dtype) -> Tensor:
     wgt = wgt / tot
     mat = np.zeros((n_out, n_in))
     np.add.at(mat, (np.repeat(np.arange(n_out), idx.shape[1]), idx.reshape(-1)), wgt.reshape(-1))
-    return torch.from_numpy(mat).to(device=device, dtype=dtype)
+    return torch.from_numpy(mat).to(device=torch.device(device), dtype=dtype)
 
 
 def blur_downsample(im_hr: Tensor, kernel: Tensor, sf: int, downsampler: str) -> Tensor:

@@ -2,9 +2,15 @@
 utils/util_net.py:27-65, which splits into four overlapping quadrants recursively and is broken at :46).
 
 Own design: a regular grid of overlapping tiles, each restored independently (batched through the same forward, so large images use
-the large-grid kernel forms), only the tile interiors kept.  With ``overlap`` >= the network's receptive-field radius the result equals
-the untiled forward; with a smaller overlap it is the usual seam-free approximation (every output pixel comes from a tile in which it
-lies at least ``overlap`` pixels from a cut, image borders excepted)."""
+the large-grid kernel forms), only the tile interiors kept.  For a purely convolutional ``forward`` (the per-pixel denoiser,
+VIRAttResUNet with noise_avg=False) and ``overlap`` >= its receptive-field radius the result equals the untiled forward; with a smaller
+overlap it is the usual seam-free approximation (every output pixel comes from a tile in which it lies at least ``overlap`` pixels
+from a cut, image borders excepted).
+
+NOT for a forward that conditions on image-global statistics: VIRAttResUNetSR (and any noise_avg=True model) pools SNet / KNet over the
+whole input (global average pools, CALayer), so each tile would get its own sigma / kernel estimate and its own SFT modulation -- visible
+tile-to-tile inconsistency, not just receptive-field truncation.  For those, estimate the conditioning once on the full image and tile
+only the restorer: ``forward_tiled_sisr`` below does that for VIRAttResUNetSR."""
 from __future__ import annotations
 
 from typing import Callable, List, Tuple
@@ -51,3 +57,32 @@ def forward_tiled(forward: Callable[[torch.Tensor], torch.Tensor], x: torch.Tens
             out[0, :, (y + t) * scale:(y + th - b) * scale, (x0 + l) * scale:(x0 + tw - r) * scale] = \
                 res[k, :, t * scale:(th - b) * scale, l * scale:(tw - r) * scale]
     return out
+
+
+def forward_tiled_sisr(net, x: torch.Tensor, sf: int, tile: int = 256, overlap: int = 16, batch: int = 8):
+    """Tiled VIRAttResUNetSR forward with GLOBAL conditioning (networks/VIRNet.py:80-97): SNet (pooled variance) and KNet (pooled kernel
+    estimate) run once on the whole low-resolution image, then only RNet -- whose SFT vectors are functions of those two estimates -- is
+    run tile by tile on the up-sampled grid.  Returns (mu, kinfo, sigma) like the module.  x is [1,c,h,w] on the device."""
+    from .. import engine
+    if x.dim() != 4 or x.shape[0] != 1:
+        raise ValueError("forward_tiled_sisr takes one image [1,c,h,w]")
+    if not net.noise_avg:
+        raise ValueError("forward_tiled_sisr is for noise_avg=True models (per-pixel conditioning tiles with forward_tiled)")
+    sf = int(sf)
+    with torch.no_grad(), torch.cuda.device(x.device):
+        x = engine._prep(x, net.SNet.in_channels)
+        sigma = engine.snet_forward(net.SNet, x, mode="sigma")                # [1,s,1,1]
+        kinfo = engine.knet_forward(net.KNet, x)                              # [1,k,1,1]
+        parts = []
+        if net.kernel_cond:
+            parts.append(kinfo.view(1, -1))
+        if net.noise_cond:
+            parts.append(sigma.view(1, -1).sqrt())
+        vec = torch.cat(parts, 1).contiguous() if parts else None
+
+        def rnet(t):
+            v = None if vec is None else vec.expand(t.shape[0], -1).contiguous()
+            return engine.rnet_forward(net.RNet, t.contiguous(), extra_vec=v, sf=sf, map_sf=sf, map_sqrt=True)
+
+        mu = forward_tiled(rnet, x, tile=tile, overlap=overlap, scale=sf, batch=batch, multiple=1 << (net.RNet.depth - 1))
+    return mu, kinfo.view(1, -1), sigma
