@@ -263,8 +263,24 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         ops.set_launch_timer(None)
+    elapsed_local = elapsed
     elapsed = vdist.max_over_ranks(elapsed, dev)
     assert torch.isfinite(mu).all()
+    # per-rank diagnostics of a multi-GPU run (one all-gather of small python objects, outside the timed region): every rank's own
+    # rate, the device it ran on (distinct UUIDs = really N GPUs), the collective library
+    diag = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device_index": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name,
+                "images_per_s": round((b - a) * args.steps / elapsed_local, 2), "seconds": round(elapsed_local, 4)}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, mine)
+        try:
+            nccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:          # (gloo rehearsal on a box without RCCL)
+            nccl = None
+        diag = {"backend": torch.distributed.get_backend(), "rccl_version": nccl, "ranks_seen": len({g["uuid"] or g["device_index"] for g in gathered}),
+                "per_rank": gathered, "broadcast_bytes": bcast_bytes, "broadcast_ms": round(bcast_ms, 3)}
 
     roof = None
     if timer is not None:
@@ -342,6 +358,7 @@ def main():
             "whole_net": {"gflop_per_image": round(gflop_img, 3), "achieved_tflops_per_gpu": round(value / world * gflop_img / 1e3, 2),
                           "frac_of_fp32_mfma_peak": round(value / world * gflop_img / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roof,
+            "multi_gpu": diag,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or sisr or training) else cpu_baseline(sd, args.size),
         }
         print(json.dumps(out), flush=True)

@@ -23,6 +23,32 @@ def test_shard_range_partitions_exactly():
         vdist.shard_range(8, 2, 2)
 
 
+def _shard_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    vdist.init(backend="gloo")
+    a, b = vdist.shard_range(256, world, rank)
+    owned = torch.zeros(256, dtype=torch.int64)
+    owned[a:b] = 1
+    dist.all_reduce(owned)                                 # how many ranks own each image
+    local = torch.arange(a, b, dtype=torch.float32).view(-1, 1)
+    full = vdist.gather_shards(local, 256)
+    ret[rank] = dict(span=(a, b), owners_min=int(owned.min()), owners_max=int(owned.max()), full_ok=bool(torch.equal(full.view(-1), torch.arange(256.0))),
+                     tmax=vdist.max_over_ranks(float(rank)))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_256_images_exactly():
+    """BASELINE configs[2]: 256 images over 8 ranks (one per GPU) -- every image owned by exactly one rank, 32 per rank, the gathered
+    result in image order, max-over-ranks timing; eight gloo processes on the CPU."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shard_worker, args=(8, port, ret), nprocs=8, join=True)
+    assert sorted(ret[r]["span"] for r in range(8)) == [(32 * r, 32 * r + 32) for r in range(8)]
+    for r in range(8):
+        assert ret[r]["owners_min"] == ret[r]["owners_max"] == 1 and ret[r]["full_ok"] and ret[r]["tmax"] == 7.0
+
+
 def _worker(rank, world, port, ret):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     vdist.init(backend="gloo")

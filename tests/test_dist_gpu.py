@@ -121,7 +121,11 @@ def test_bench_self_spawns_two_ranks():
     assert d["config"]["global_batch"] == 64 and d["config"]["images_per_gpu"] == 32
     assert "42157328 B" in d["config"]["parallelism"]              # the one flat weight broadcast: 10 539 332 fp32 parameters
     assert d["value"] > 0 and d["value"] == pytest.approx(64 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-3)
-    assert 0.0 < d["roofline"]["frac"] <= 1.0
+    assert 0.0 < d["roofline"]["frac"] <= 1.0 and 0.0 < d["roofline"]["frac_algorithmic"] <= d["roofline"]["frac"]
+    mg = d["multi_gpu"]                                               # per-rank diagnostics of an N-rank line
+    assert mg["backend"] == "gloo" and len(mg["per_rank"]) == 2 and sorted(r["rank"] for r in mg["per_rank"]) == [0, 1]
+    assert mg["ranks_seen"] == 1                                      # both ranks share this box's one GPU (8 distinct UUIDs on the 8-GPU node)
+    assert all(r["images_per_s"] > 0 for r in mg["per_rank"]) and mg["broadcast_bytes"] == 42157328 and mg["broadcast_ms"] > 0
 
 
 def test_bench_train_two_ranks_averages_gradients():
