@@ -142,6 +142,39 @@ def build(nrep, ji, pre):
     return ops, nm
 
 
+def build_final(nrep, ji):
+    """stages of the LAST chunk: there is no next chunk to stage, so stage 0 only finishes positions {2,5} (+ halo pair 2), stages 1 and 2
+    only read and multiply, and stage 2 -- whose weights' successor does not exist either -- requests the epilogue's first operand tile
+    (residual or mask, micro-operation epf(i) = one 16-byte load per thread) into the registers the staging no longer needs"""
+    ng, nm = 3 * nrep, 9 * nrep
+    ndi = (12 * nrep + 7) // 8
+    ops = []
+    reads = []
+    for dy in range(3):
+        reads.append(("rdB%d" % dy, "rdB(%s);" % I(dy), 3 * nrep * dy))
+    for g in range(ng):
+        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), 3 * g))
+    for name, code, use in sorted(reads, key=lambda r: r[2]):
+        o = Op(name, code, 2, kind="ldsr")
+        o.deadline = max(0, use - LDS_LAT)
+        ops.append(o)
+    if ji < 2:
+        dma = [Op("dma%d" % i, "dma(%s);" % I(i), 4, kind="dma") for i in range(ndi)]
+        for i, d in enumerate(dma):
+            d.earliest = 1 + i
+        ops += dma
+    if ji == 0:
+        stg = []
+        put_ops(0, 2, stg)
+        put_ops(1, 5, stg)
+        halo_ops(2, stg)
+        ops += stg
+    if ji == 2:
+        for i in range(8):
+            ops.append(Op("epf%d" % i, "epf(%s);" % I(i), 3, earliest=1 + i, kind="vmem"))
+    return ops, nm
+
+
 def schedule(ops, nm):
     load = [0] * (nm + 1)
     by = {o.name: o for o in ops}
@@ -174,10 +207,13 @@ def schedule(ops, nm):
 
 
 def emit(nrep, ji, pre, out):
-    ops, nm = build(nrep, ji, pre)
+    if pre is None:
+        ops, nm = build_final(nrep, ji)
+    else:
+        ops, nm = build(nrep, ji, pre)
     load = schedule(ops, nm)
     order = {"ldsr": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
-    out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre))
+    out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre) if pre is not None else "#define WX4_FINAL_%d_%d \\" % (nrep, ji))
     for s in range(nm + 1):
         here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])
         line = "  SB(); " + " ".join(o.code for o in here) + " SB();"
@@ -192,11 +228,13 @@ def emit(nrep, ji, pre, out):
 
 def main():
     out = ["// GENERATED by tools/gen_wx4_sched.py (CAP=%d, LDS_LAT=%d, HEAD_CAP=%d) -- do not edit; see that script for the model." % (CAP, LDS_LAT, HEAD_CAP),
-           "// WX4_STAGE_<NREP>_<ji>_<PRE>: the body of one stage of conv_wx4_kernel as fenced issue slots, one per MFMA.", ""]
+           "// WX4_STAGE_<NREP>_<ji>_<PRE>: the body of one stage of conv_wx4_kernel as fenced issue slots, one per MFMA;",
+           "// WX4_FINAL_<NREP>_<ji>: the same for the stages of the last chunk (nothing to stage for a next one).", ""]
     for nrep in (1, 2, 3):
         for ji in range(3):
             for pre in (0, 1, 2):
                 emit(nrep, ji, pre, out)
+            emit(nrep, ji, None, out)
     sys.stdout.write("\n".join(out) + "\n")
 
 

@@ -52,6 +52,11 @@ def main():
     if st[:, 6].any():
         print(f"epilogue split (median cycles after the K loop): first exchange written + barrier {np.median(st[:, 6] - st[:, 2]):.0f}, "
               f"slab 0 stored {np.median(st[:, 7] - st[:, 2]):.0f}, exit {np.median(ep):.0f}")
+    # are the CUs' epilogues in step?  K-loop end times modulo the median tile period, 8 bins (flat = desynchronised)
+    period = float(np.median(st[:, 3] - st[:, 0]))
+    ph = ((st[:, 2] - st[:, 0].min()) % period) / period
+    hist = np.histogram(ph, bins=8, range=(0, 1))[0]
+    print(f"tile period {period:.0f} cycles; K-loop end phase histogram (8 bins): {hist.tolist()}; span of all tiles {st[:, 3].max() - st[:, 0].min()} cycles")
     acc = t[nwg * 8:nwg * 8 + nwg * 8 * 32].reshape(-1, 8, 32).astype(np.float64) / nst
     acc = acc[acc[:, 0, 0] != 0]
     print("cycles per MFMA group (3 MFMAs + the slots in front of them), g = 0..8, then tail + waits + barrier; median over workgroups")

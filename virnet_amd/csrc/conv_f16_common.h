@@ -57,8 +57,10 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
 __device__ __forceinline__ void range_note(float& amax, const f32x4& a, const f32x4& b) {
   amax = fmaxf(fmaxf(amax, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fmaxf(fabsf(a.z), fabsf(a.w)), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
 }
+// (a plain store through a GLOBAL-address-space pointer: an atomic on the generic pointer is a FLAT instruction, and one pending FLAT
+// operation -- even on a path never taken -- makes hipcc turn the next wait of the epilogue into vmcnt(0) lgkmcnt(0))
 __device__ __forceinline__ void range_report(int* flag, float amax) {
-  if (flag != nullptr && amax >= 65520.f) atomicOr(flag, 1);
+  if (flag != nullptr && amax >= 65520.f) *(__attribute__((address_space(1))) int*)flag = 1;
 }
 
 // v = hi + lo in fp16 (round to nearest even both times)

@@ -24,8 +24,11 @@
 //       the NEXT chunk's values into them during the following stage (raw pixels are held in registers across the three stages).
 //   U (LDS, 2 x 12*NREP KB): stage = positions {ji, 3+ji} x 3 row taps x NREP slabs x (hi|lo) fragments of 1 KB, streamed by DMA
 //       (global_load_lds_dwordx4) one stage ahead, double buffered; one barrier per stage (9*NREP MFMAs per wave).
-//   Staging: thread = (row, x-tile, channel quad); the tile's 18 V rows are 9 wave-items for 8 waves -- the two halo rows are a second
-//       item of ONE wave, rotating with the chunk.
+//   Staging: thread = (V row 0..15, x-tile, channel quad): 6 pixels x 4 channels -> 6 positions x 4 channels; the tile's two halo rows
+//       (V rows 16, 17) are 512 values per position pair = ONE extra scalar value per thread and stage.  All of it -- pixel loads,
+//       pre-activation, rows of B^T, the exact hi/lo split, LDS stores, the DMA pieces, the fragment reads -- is cut into
+//       micro-operations (the lambdas below) that tools/gen_wx4_sched.py places into the issue slots between the MFMAs of a stage
+//       (conv_f16_wx4_sched.inc; every slot fenced with sched_barrier: hipcc's own scheduler clumps the VALU work and sinks the reads).
 // Epilogue: the inverse transform crosses the two waves of a row block, so per 32-channel slab every wave writes three pre-combined
 // blocks ([pixel][channel] records) to LDS and each thread finishes (pixel, channel quad) items from two or three of them: the same
 // round trip also turns the tile around for 128-byte runs in the NHWC store.  Inverse scale, bias, mask, residual, activation as conv_f16.hip.
@@ -44,12 +47,7 @@ constexpr int WX_POS = 2 * WX_PLANE;
 constexpr int WX_VBYTES = 6 * WX_POS;        // 55296
 constexpr int WX_XBLK = 32 * 144 + 64;       // exchange block: [32 columns][32 channels + 16 B pad], skewed by 64 B against its neighbours
 constexpr int WX_CHUNK_BYTES = 36 * 1024;
-#ifndef WX_HEAD_VALU
-#define WX_HEAD_VALU 24      // staging VALU ops issued behind the first fragment reads of a stage (they cover the LDS latency)
-#endif
-#ifndef WX_GAP_VALU
-#define WX_GAP_VALU 10       // ... and behind every group of three MFMAs
-#endif    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
+// one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB] = WX_CHUNK_BYTES
 
 template <int J>
 __device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
@@ -113,6 +111,8 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const v_lds = smem;
   char* const w_lds = smem + WX_VBYTES;
+  constexpr int LDS_MAIN = WX_VBYTES + 2 * USTAGE > 24 * WX_XBLK ? WX_VBYTES + 2 * USTAGE : 24 * WX_XBLK;
+  float* const sb_lds = reinterpret_cast<float*>(smem + LDS_MAIN);   // [inverse scale | bias] of the NB channels: read back by the epilogue
 
   // ---- workgroup -> (tile, channel block): contiguous tile ranges per XCD (block b runs on XCD b%8), channel blocks adjacent
   const int ncb = a.NP / NB;
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
   for (int jw = 0; jw < 3; ++jw)
 #pragma unroll
-    for (int b = 0; b < 6; ++b) hc[jw][b] = hp ? wx4_coef(jw + 3, b) : wx4_coef(jw, b);
+    for (int b = 0; b < 6; ++b)                      // (readfirstlane: keeps the 18 coefficients in scalar registers)
+      hc[jw][b] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hp ? wx4_coef(jw + 3, b) : wx4_coef(jw, b))));
   char* const vh_lds = v_lds + hp * 3 * WX_POS;
 
   const float* const imul = PRE == 2 ? a.in_mul + (size_t)img * a.Cin : nullptr;
@@ -337,6 +338,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       for (int r = 0; r < 16; ++r) acc[j][nr][r] = 0.f;
 
   // ---- prologue: weights of stage 0 by DMA; chunk 0's pixels -> positions {0,3} and {1,4} ({2,5} are written by stage 0 itself)
+  const int nbase = a.slab_base * 32 + cb * NB;
+  float sbv = 0.f;                                 // this thread's entry of the [inverse scale | bias] table
+  if (tid < NB) sbv = a.inv_scale[nbase + tid];
+  else if (tid < 2 * NB && a.bias) sbv = a.bias[nbase + tid - NB];
 #pragma unroll
   for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds);
   ldp(WX_I(0)); ldp(WX_I(1)); ldp(WX_I(2)); ldp(WX_I(3)); ldp(WX_I(4)); ldp(WX_I(5));
@@ -353,6 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   pA(WX_I(1), WX_I(4)); pB(WX_I(1), WX_I(4)); pV(WX_I(1), WX_I(4)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(4));
   hSa(WX_I(0)); hSb(WX_I(0)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(0));
   hSa(WX_I(1)); hSb(WX_I(1)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(1));
+  if (tid < 2 * NB) sb_lds[tid] = sbv;
   __syncthreads();
   TSTAMP(1);
 
@@ -367,8 +373,20 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #ifdef VIRNET_F16_TIMING
   long long wx_tg[3][10] = {};
 #endif
-  auto stage = [&](int c, auto jic) {
+  // The stages of the LAST chunk (fin) have no next chunk to stage: stage 0 only finishes positions {2,5}, stages 1 and 2 read and
+  // multiply, and stage 2 requests the epilogue's first operand tile (epf) into the registers the staging has released.
+  constexpr int NIT = 8;                            // epilogue items of a thread: row pairs
+  constexpr bool EPF = EPI == 1 || EPI == 2;        // ONE operand tile (residual or mask): prefetched slab by slab
+  unsigned yoff[NIT];
+  f32x4 op1[EPF ? NREP : 1][NIT];
+  decltype(__builtin_amdgcn_make_buffer_rsrc((float*)nullptr, 0, 0, 0)) op1rs;
+  auto epf = [&](auto ic) {
+    constexpr int it = decltype(ic)::value;
+    if constexpr (EPF) op1[0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it], 0, 0));
+  };
+  auto stage = [&](int c, auto jic, auto finc) {
     constexpr int ji = decltype(jic)::value;
+    constexpr bool fin = decltype(finc)::value;
     const int s = c * 3 + ji;
     const char* const wb = w_lds + (s & 1) * USTAGE + a_base;
     char* const wn = w_lds + ((s + 1) & 1) * USTAGE;
@@ -402,8 +420,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #else
 #define WX_TS(g) do { } while (0)
 #endif
-#define WX_STAGE_CASE(N_, J_, P_) if constexpr (NREP == N_ && ji == J_ && PRE == P_) { WX4_STAGE_##N_##_##J_##_##P_ }
-#define WX_STAGE_PRE(N_, J_) WX_STAGE_CASE(N_, J_, 0) WX_STAGE_CASE(N_, J_, 1) WX_STAGE_CASE(N_, J_, 2)
+#define WX_STAGE_CASE(N_, J_, P_) if constexpr (!fin && NREP == N_ && ji == J_ && PRE == P_) { WX4_STAGE_##N_##_##J_##_##P_ }
+#define WX_STAGE_PRE(N_, J_) WX_STAGE_CASE(N_, J_, 0) WX_STAGE_CASE(N_, J_, 1) WX_STAGE_CASE(N_, J_, 2) \
+    if constexpr (fin && NREP == N_ && ji == J_) { WX4_FINAL_##N_##_##J_ }
     WX_STAGE_PRE(1, 0) WX_STAGE_PRE(1, 1) WX_STAGE_PRE(1, 2)
     WX_STAGE_PRE(2, 0) WX_STAGE_PRE(2, 1) WX_STAGE_PRE(2, 2)
     WX_STAGE_PRE(3, 0) WX_STAGE_PRE(3, 1) WX_STAGE_PRE(3, 2)
@@ -411,18 +430,44 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #undef WX_STAGE_CASE
     // end of stage: this wave's DMA pieces have landed (they are older than the pixel loads of stage 0, which stay in flight), its
     // LDS writes are done; then the workgroup barrier
-    if constexpr (ji == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
+    // (last chunk: no pixel loads behind stage 0's pieces; stage 2 issued no piece, and the operand tile it requested stays in flight)
+    if constexpr (ji == 0 && !fin) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
+    else if constexpr (ji == 2 && fin) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (ji == 1 && fin) {
+      // a wait hipcc can SEE (the asm ones are opaque to it): a weight piece is a FLAT instruction that writes LDS, and while the
+      // compiler believes one is pending it turns every wait it inserts into vmcnt(0) -- here that would be the epilogue's first wait
+      // for its operand tile, with the next tile's requests already behind it
+      __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
+      asm volatile("s_barrier" ::: "memory");
+    }
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef VIRNET_F16_TIMING
     wx_tg[ji][9] += (long long)__builtin_amdgcn_s_memtime() - wx_tprev;       // tail slot + waits + barrier
 #endif
 #undef WX_TS
   };
-  for (int c = 0; c < nch; ++c) {
-    stage(c, WX_I(0));
-    stage(c, WX_I(1));
-    stage(c, WX_I(2));
+  using No = std::false_type;
+  using Yes = std::true_type;
+  for (int c = 0; c + 1 < nch; ++c) {
+    stage(c, WX_I(0), No{});
+    stage(c, WX_I(1), No{});
+    stage(c, WX_I(2), No{});
   }
+  stage(nch - 1, WX_I(0), Yes{});
+  stage(nch - 1, WX_I(1), Yes{});
+  // epilogue reader: thread = (pixel column x of the tile, channel quad cq), items it = row pairs.  One 32-bit byte offset per item
+  // serves the operand loads and the stores (buffer instructions; an item outside the image gets an out-of-range offset: loads 0,
+  // stores nothing).
+  const int cq = tid & 7, px = (tid >> 3) & 31, prow = tid >> 8;
+  const int C = a.cout;
+  const size_t img_off = (size_t)img * a.H * a.W * C;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int oy = oy0 + 2 * it + prow, ox = ox0 + px;
+    yoff[it] = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * C + nbase + cq * 4) * 4u : 0x80000000u;
+  }
+  if constexpr (EPF) op1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI == 1 ? a.res : a.mask) + img_off), 0, a.H * a.W * C * 4, 0x00020000);
+  stage(nch - 1, WX_I(2), Yes{});
   TSTAMP(2);
   range_report(a.range_flag, amax);
 #ifdef VIRNET_F16_TIMING
@@ -457,9 +502,6 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     }
     put_block(0, b0); put_block(1, b1); put_block(2, b2);
   };
-  // reader: thread = (pixel column x of the tile, channel quad cq), items it = row pairs
-  constexpr int NIT = 8;
-  const int cq = tid & 7, px = (tid >> 3) & 31, prow = tid >> 8;
   const int pk = px & 3, pxt = px >> 2;
   const int r_p = ((pk == 0) ? 0 : (pk == 2) ? 2 : 1) * WX_XBLK + pxt * 144 + cq * 16;
   const int r_q = (3 + (pk & 1)) * WX_XBLK + pxt * 144 + cq * 16;
@@ -472,98 +514,80 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     const f32x4 e = *reinterpret_cast<const f32x4*>(xb + base + r_e);
     return p + ck * qv + ek * e;
   };
-  const int nbase = a.slab_base * 32 + cb * NB;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int C = a.cout;
-  const size_t img_off = (size_t)img * a.H * a.W * C;
-  unsigned eoff[NIT];
-  bool eok[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int oy = oy0 + 2 * it + prow, ox = ox0 + px;
-    eok[it] = oy < a.H && ox < a.W;
-    eoff[it] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)(nbase + cq * 4);
-  }
   auto mask4 = [&](f32x4 v, f32x4 m) {
     return f32x4{m.x > 0.f ? v.x : v.x * a.mask_slope, m.y > 0.f ? v.y : v.y * a.mask_slope,
                  m.z > 0.f ? v.z : v.z * a.mask_slope, m.w > 0.f ? v.w : v.w * a.mask_slope};
   };
+  // inverse scale / bias of the thread's channel quad: from the table the prologue left in LDS (no global load in the epilogue's way)
+  auto inv_of = [&](int nr) { return *reinterpret_cast<const f32x4*>(sb_lds + nr * 32 + cq * 4); };
+  auto bias_of = [&](int nr) { return *reinterpret_cast<const f32x4*>(sb_lds + NB + nr * 32 + cq * 4); };
   if constexpr (EPI < 4) {
-    // ONE stored tensor.  Every global load of the tile is requested before the first store (conv_f16.hip: loads and stores share one
-    // counter that must be treated as out of order once both kinds are pending); EPI 3 cannot hold two operand tiles and loads per slab.
+    // ONE stored tensor.  gfx950 counts loads and stores on one vmcnt that must be treated as out of order once both kinds are
+    // pending (conv_f16.hip), so a load consumed while stores are pending costs vmcnt(0).  With ONE operand tile (residual or mask; EPF)
+    // slab 0's tile was requested in the K loop's last stage, slab 1's follows the first exchange write (its accumulators are free
+    // then) and slab nr+2's goes out in front of slab nr's stores: the vmcnt(0) happens once, in slab 1, when everything outstanding is
+    // a whole exchange phase old.  EPI 3 (mask AND residual) cannot hold the tiles and loads per slab.
     constexpr bool RES = (EPI & 1) != 0, MASK = (EPI & 2) != 0;
-    const float* const rimg = a.res + img_off;
-    const float* const mimg = a.mask + img_off;
     float* const y = (a.y_act ? a.y_act : a.y_raw) + img_off;
     const float slope_eff = a.y_act ? a.slope : 1.f;
-    const float* const bp = a.bias ? a.bias : a.inv_scale;
-    const float hb = a.bias ? 1.f : 0.f;
-    // The operand tile of slab nr+1 (residual or mask) is requested at the start of slab nr's read phase, BEFORE that slab's stores: a
-    // load consumed behind pending stores waits for their acknowledgement (one in-order counter for both), and by the time slab nr+1
-    // is consumed the only stores ahead of its loads are those of slab nr-1, a whole phase old.  Two operand tiles live at most.
-    constexpr bool ONE = EPI == 1 || EPI == 2;
-    f32x4 bias4[NREP], inv4[NREP], op1[2][NIT];
-    const float* const op1p = RES ? rimg : mimg;
     auto load_op1 = [&](int nr) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) op1[nr & 1][it] = *reinterpret_cast<const f32x4*>(op1p + eoff[it] + nr * 32);
+      for (int it = 0; it < NIT; ++it)
+        op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, 0));
     };
-#pragma unroll
-    for (int nr = 0; nr < NREP; ++nr) {
-      inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nbase + nr * 32 + cq * 4);
-      bias4[nr] = *reinterpret_cast<const f32x4*>(bp + nbase + nr * 32 + cq * 4);
-    }
-    if (ONE) load_op1(0);
-    SB();
     xwrite(0);
+    if (EPF && NREP > 1) load_op1(1);
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
-    unsigned yoff[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) yoff[it] = eok[it] ? eoff[it] * 4u : 0x80000000u;
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       if (nr > 0) xwrite(nr);
       wx_lds_barrier();
       if (nr == 0) TSTAMP(6);
-      if (ONE && nr + 1 < NREP) load_op1(nr + 1);
       f32x4 mv[NIT], rv[NIT];
-      if (EPI == 3) {
+      if constexpr (EPI == 3) {
+        const auto mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask + img_off), 0, a.H * a.W * C * 4, 0x00020000);
+        const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res + img_off), 0, a.H * a.W * C * 4, 0x00020000);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          mv[it] = *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32);
-          rv[it] = *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
+          mv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mrs, yoff[it] + nr * 128, 0, 0));
+          rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrs, yoff[it] + nr * 128, 0, 0));
         }
       }
-      const f32x4 b4 = bias4[nr] * hb;
+      const f32x4 i4 = inv_of(nr), b4 = bias_of(nr);
       f32x4 tv[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) tv[it] = xread(it);
-      SB();                                          // (the next slab's operand requests stay above this slab's stores)
+      SB();
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        f32x4 v = tv[it] * inv4[nr] + b4;
-        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[nr & 1][it]);
-        if (RES) v += EPI == 3 ? rv[it] : op1[nr & 1][it];
-        v = lrelu4(v, slope_eff);
-        // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
+        f32x4 v = tv[it] * i4 + b4;
+        if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[EPF ? nr : 0][it]);
+        if (RES) v += EPI == 3 ? rv[it] : op1[EPF ? nr : 0][it];
+        tv[it] = lrelu4(v, slope_eff);
       }
+      SB();
+      if (EPF && nr + 2 < NREP) load_op1(nr + 2);
+      SB();                                          // (the operand requests stay above this slab's stores)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
       if (nr == 0) TSTAMP(7);
       if (nr + 1 < NREP) wx_lds_barrier();
     }
   } else {
     // generic form (two stored tensors and / or SFT on the output): optional operands by runtime pointer
-    const float* const rimg = a.res ? a.res + img_off : nullptr;
-    const float* const mimg = a.mask ? a.mask + img_off : nullptr;
-    float* const yraw = a.y_raw ? a.y_raw + img_off : nullptr;
-    float* const yact = a.y_act ? a.y_act + img_off : nullptr;
+    const char* const rimg = a.res ? reinterpret_cast<const char*>(a.res + img_off) : nullptr;
+    const char* const mimg = a.mask ? reinterpret_cast<const char*>(a.mask + img_off) : nullptr;
+    char* const yraw = a.y_raw ? reinterpret_cast<char*>(a.y_raw + img_off) : nullptr;
+    char* const yact = a.y_act ? reinterpret_cast<char*>(a.y_act + img_off) : nullptr;
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       xwrite(nr);
       wx_lds_barrier();
       const int co = nbase + nr * 32 + cq * 4;
-      const f32x4 inv4 = *reinterpret_cast<const f32x4*>(a.inv_scale + co);
-      const f32x4 bias4 = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co) : zero4;
+      const f32x4 inv4 = inv_of(nr), bias4 = bias_of(nr);
       f32x4 mul4 = f32x4{1.f, 1.f, 1.f, 1.f}, add4 = zero4;
       if (a.mul) {                                           // SFT on the output (AttResUNet.py:57-58): SISR down path
         mul4 = *reinterpret_cast<const f32x4*>(a.mul + (size_t)img * C + co);
@@ -572,11 +596,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         f32x4 v = xread(it) * inv4 + bias4;
-        if (eok[it]) {
-          if (mimg) v = mask4(v, *reinterpret_cast<const f32x4*>(mimg + eoff[it] + nr * 32));
-          if (rimg) v += *reinterpret_cast<const f32x4*>(rimg + eoff[it] + nr * 32);
-          if (yraw) *reinterpret_cast<f32x4*>(yraw + eoff[it] + nr * 32) = v;
-          if (yact) *reinterpret_cast<f32x4*>(yact + eoff[it] + nr * 32) = lrelu4(v * mul4 + add4, a.slope);
+        if (yoff[it] != 0x80000000u) {
+          const unsigned o = yoff[it] + nr * 128;
+          if (mimg) v = mask4(v, *reinterpret_cast<const f32x4*>(mimg + o));
+          if (rimg) v += *reinterpret_cast<const f32x4*>(rimg + o);
+          if (yraw) *reinterpret_cast<f32x4*>(yraw + o) = v;
+          if (yact) *reinterpret_cast<f32x4*>(yact + o) = lrelu4(v * mul4 + add4, a.slope);
         }
       }
       if (nr + 1 < NREP) wx_lds_barrier();
@@ -589,7 +614,7 @@ template <int NREP, int EPI, int PRE>
 int launch_wx4(FArgs k, hipStream_t st) {
   constexpr int LDS_K = WX_VBYTES + 2 * 12 * NREP * 1024;
   constexpr int LDS_E = 24 * WX_XBLK;
-  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
+  constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 2 * 32 * NREP * 4;      // + the channel block's inverse scales and biases
   static_assert(LDS <= 160 * 1024, "one workgroup per CU");
   static unsigned long long attr_done = 0;
   auto kern = conv_wx4_kernel<NREP, EPI, PRE>;
