@@ -13,11 +13,14 @@ Micro-operations (names = lambdas in the kernel; X = put context 0/1, J = Winogr
   rdA(g) rdB(dy)            fragment reads (LDS)
   pA/pB/pV(X,J)             the rows of B^T on the thread's 6 pixels x 4 channels      pHi/pSub/pLo(X) fp16 split   pSt(X,J) LDS store
   hSa/hSb/hV(JW) hHi hSub hLo hSt(JW)   the same for the thread's one halo value
-  prM(b) prX(b) prHa prHb   pre-activation (stage 1)            ldp(b) ldh(b) ldsft   pixel loads of the next chunk (stage 0)
+  pr(b) prHa prHb           pre-activation (stage 1)            ldp(b) ldh(b) ldsft   pixel loads of the next chunk (stage 0)
   dma(i)                    one 1-KB piece of the next stage's weights
-Stage 0 writes positions {2,5} (+ halo pair 2) and then requests the next chunk's pixels (the DMA pieces are issued BEFORE them: the
-end-of-stage wait counts on it); stage 1 pre-activates -- every first touch of a loaded register before the stage's first DMA piece,
-because the compiler's wait for a pixel load becomes vmcnt(0) once a DMA piece is pending -- and writes {0,3}; stage 2 writes {1,4}.
+Stage 0 writes positions {2,5} (+ halo pair 2) and requests the next chunk's pixels as soon as the old ones have been read (the DMA
+pieces are issued BEFORE them: the end-of-stage wait vmcnt(pixel loads) counts on it); stage 1 pre-activates and writes {0,3}, touching
+the new pixels from slot S1_START on (one stage after their request: HBM latency under load is about a stage); stage 2 writes {1,4}.
+The kernel's end-of-stage waits are the s_waitcnt BUILTIN, so hipcc knows that no weight piece is pending when a stage starts and its own
+waits for the pixel registers are exact (with asm waits every one of them became vmcnt(0), and the first touches had to sit in front of
+the stage's first piece).
 
 Usage: python tools/gen_wx4_sched.py > virnet_amd/csrc/conv_f16_wx4_sched.inc      (knobs: CAP, LDS_LAT below)"""
 import sys
@@ -25,6 +28,8 @@ import sys
 CAP = 5        # issue units per slot (an MFMA hides about five single-issue instructions)
 LDS_LAT = 3    # slots between a fragment read and the MFMA that consumes it
 HEAD_CAP = 14  # slot 0 sits behind the barrier, in front of the first MFMA which waits for its fragments anyway
+S1_START = int(__import__("os").environ.get("WX4_S1_START", "8"))   # stage 1: first slot that touches the pixels requested in stage 0
+S1_START_PRE = int(__import__("os").environ.get("WX4_S1_START_PRE", "3"))   # ... when they are pre-activated first (more work to place)
 
 
 class Op:
@@ -86,40 +91,32 @@ def build(nrep, ji, pre):
         rd = put_ops(0, 2, stg) + put_ops(1, 5, stg) + halo_ops(2, stg)
         lds = []
         for b in range(6):
-            lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(r, 1) for r in rd] + [(d.name, 1) for d in dma], kind="vmem"))
+            lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "p"] + [(d.name, 0) for d in dma], kind="vmem"))
         for b in range(6):
-            lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [(r, 1) for r in rd] + [(d.name, 1) for d in dma], kind="vmem"))
+            lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "h"] + [("ldp5", 0)] + [(d.name, 0) for d in dma], kind="vmem"))
         if pre == 2:
-            lds.append(Op("ldsft", "ldsft();", 4, [(d.name, 1) for d in dma], kind="vmem"))
-        # the DMA pieces go first (they must be older than the pixel loads), one per slot from slot 1 on
+            lds.append(Op("ldsft", "ldsft();", 4, [(d.name, 0) for d in dma], kind="vmem"))
+        # the DMA pieces go first (they must be older than the pixel loads: the end-of-stage wait counts on it), one per slot from slot
+        # 1 on; then whatever still reads the OLD pixels, then the loads -- the sooner they leave, the more of their latency stage 0
+        # hides -- and the rest of the position work behind them
         for i, d in enumerate(dma):
             d.earliest = 1 + i
-        ops += dma + stg + lds
+        first = [o for o in stg if o.name in rd]
+        rest = [o for o in stg if o.name not in rd]
+        ops += dma + first + lds + rest
     elif ji == 1:
-        first = []
+        # the pixels requested in stage 0 are touched from slot S1_START on (the compiler's waits for them are exact now that the
+        # end-of-stage waits are visible to it: gen header), pre-activation first
         if pre >= 1:
+            t0 = S1_START_PRE
             for b in range(6):
-                # (prM(b) writes the temporary that prX(b-2) reads)
-                stg.append(Op("prM%d" % b, "prM(%s);" % I(b), 2 if pre == 1 else 4, [("prX%d" % (b - 2), 1)] if b >= 2 else []))
-                first.append("prM%d" % b)
-                if b >= 1:
-                    stg.append(Op("prX%d" % (b - 1), "prX(%s);" % I(b - 1), 4 if pre == 1 else 8, [("prM%d" % (b - 1), 1)]))
-            stg.append(Op("prX5", "prX(%s);" % I(5), 4 if pre == 1 else 8, [("prM5", 1)]))
-            stg.append(Op("prHa", "prHa();", 6))
-            stg.append(Op("prHb", "prHb();", 6))
-            first += ["prHa", "prHb"]
-            pdeps = [("prX%d" % b, 1) for b in range(6)]
+                stg.append(Op("pr%d" % b, "pr(%s);" % I(b), 6 if pre == 1 else 12, earliest=t0))
+            stg.append(Op("prHa", "prHa();", 6, earliest=t0))
+            stg.append(Op("prHb", "prHb();", 6, earliest=t0))
+            pdeps = [("pr%d" % b, 1) for b in range(6)]
             hdeps = [("prHa", 1), ("prHb", 1)]
         else:
-            # no pre-activation: the first touch of the loaded registers is a cheap copy-free marker (mask only when PRE == 2)
-            for b in range(6):
-                stg.append(Op("prX%d" % b, "prX(%s);" % I(b), 1))
-                first.append("prX%d" % b)
-            stg.append(Op("prHa", "prHa();", 1))
-            stg.append(Op("prHb", "prHb();", 1))
-            first += ["prHa", "prHb"]
-            pdeps = [("prX%d" % b, 1) for b in range(6)]
-            hdeps = [("prHa", 1), ("prHb", 1)]
+            pdeps, hdeps = [], []
         p0 = len(stg)
         put_ops(0, 0, stg)
         put_ops(1, 3, stg)
@@ -127,11 +124,13 @@ def build(nrep, ji, pre):
         for o in stg[p0:]:
             if o.name in ("pA0", "pA1", "pB1", "pV0"):
                 o.deps += pdeps
+                o.earliest = S1_START
             if o.name in ("hSa", "hSb"):
                 o.deps += hdeps
-        for d in dma:
-            d.deps += [(f, 1) for f in first]
-        ops += stg[:p0] + dma + stg[p0:]          # (the DMA pieces right behind the first touches, ahead of the position work)
+                o.earliest = S1_START
+        for i, d in enumerate(dma):
+            d.earliest = 1 + i
+        ops += dma + stg
     else:
         put_ops(0, 1, stg)
         put_ops(1, 4, stg)

@@ -10,5 +10,5 @@ for v in "$@"; do
 done
 done
 if [ -f virnet_amd/lib/libvirnet_hip_timing.so ]; then
-for m in pre res; do echo "== timeline $m"; VIRNET_HIP_LIB=$PWD/virnet_amd/lib/libvirnet_hip_timing.so python tools/wx4_timeline.py --shape l0 --mode $m 2>&1 | grep -v amdgpu.ids | head -4; done
+for m in pre res; do echo "== timeline $m"; VIRNET_HIP_LIB=$PWD/virnet_amd/lib/libvirnet_hip_timing.so python tools/wx4_timeline.py --shape l0 --mode $m 2>&1 | grep -v amdgpu.ids | head -12; done
 fi

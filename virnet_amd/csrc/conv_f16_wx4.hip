@@ -195,27 +195,15 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       sah = iadd[(ld_so >> 2) + hch];
     }
   };
-  // pre-activation (AttResUNet.py:54-55): prM forms slope*x (the first touch of the loaded register), prX takes the maximum one slot later
-  f32x4 pt[2];
-  auto prM = [&](auto bc) {
+  // pre-activation (AttResUNet.py:54-55) of one loaded pixel quad: lrelu(x * mul + add), zero outside the image AFTER it
+  auto pr = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    if constexpr (PRE == 2) d0[b] = d0[b] * sm + sa;
-    pt[b & 1] = d0[b] * in_slope_eff;
-  };
-  auto prX = [&](auto bc) {
-    constexpr int b = decltype(bc)::value;
-    if constexpr (PRE == 0) {
-      f32x4 t = d0[b];                                // (the compiler's wait for this load belongs here, ahead of the stage's DMA pieces)
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("" : "+v"(t));
-#endif
-      d0[b] = t;
-    } else {
-      const f32x4 t = pt[b & 1];
-      f32x4 v = f32x4{vmax(d0[b].x, t.x), vmax(d0[b].y, t.y), vmax(d0[b].z, t.z), vmax(d0[b].w, t.w)};
-      if constexpr (PRE == 2) v = ((it0.inb >> b) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      d0[b] = v;
-    }
+    f32x4 x = d0[b];
+    if constexpr (PRE == 2) x = x * sm + sa;
+    const f32x4 t = x * in_slope_eff;
+    f32x4 v = f32x4{vmax(x.x, t.x), vmax(x.y, t.y), vmax(x.z, t.z), vmax(x.w, t.w)};
+    if constexpr (PRE == 2) v = ((it0.inb >> b) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    d0[b] = v;
   };
   auto prH = [&](int b0) {
 #pragma unroll
@@ -274,10 +262,19 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     pc[X].l0 = cvtpk(pc[X].a.x, pc[X].a.y);
     pc[X].l1 = cvtpk(pc[X].a.z, pc[X].a.w);
   };
+  // The V stores are written as asm: hipcc orders every LDS STORE it can see behind all pending weight pieces (an LDS-DMA piece is a
+  // store to LDS for its wait-count pass: WAW), i.e. it puts s_waitcnt vmcnt(0) in front of the first store of every stage -- a wait for
+  // the pieces just issued (and in stage 0 nothing else may be pending then).  The planes written here are dead planes of V, the pieces
+  // go to U, and the end-of-stage wait covers lgkmcnt.
+  const unsigned st_main = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(v_lds + it0.dst);
   auto pSt = [&](auto xc, auto jc) {
     constexpr int X = decltype(xc)::value, J = decltype(jc)::value;
-    *reinterpret_cast<uint2*>(v_lds + J * WX_POS + it0.dst) = make_uint2(pc[X].h0, pc[X].h1);
-    *reinterpret_cast<uint2*>(v_lds + J * WX_POS + WX_PLANE + it0.dst) = make_uint2(pc[X].l0, pc[X].l1);
+    const uint2 hi = make_uint2(pc[X].h0, pc[X].h1), lo = make_uint2(pc[X].l0, pc[X].l1);
+    const unsigned ad = st_main;                     // (asm operands of a generic lambda must be its own locals)
+    static_assert(WX_POS % 512 == 0 && WX_PLANE % 512 == 0, "ds_write2st64_b64 offsets are in units of 512 bytes");
+    asm volatile("ds_write2st64_b64 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(ad), "v"(hi), "v"(lo), "n"(J * WX_POS / 512),
+                 "n"((J * WX_POS + WX_PLANE) / 512)
+                 : "memory");
   };
   // the thread's halo value of position pair JW
   float hv = 0.f, hw = 0.f;
@@ -294,10 +291,13 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   auto hHi = [&]() { amax = fmaxf(amax, fabsf(hv)); hhi = (_Float16)hv; };
   auto hSub = [&]() { hw = hv - (float)hhi; };
   auto hLo = [&]() { hlo = (_Float16)hw; };
+  const unsigned st_halo = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(vh_lds + ith.dst);
   auto hSt = [&](auto jwc) {
     constexpr int JW = decltype(jwc)::value;
-    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + ith.dst) = hhi;
-    *reinterpret_cast<_Float16*>(vh_lds + JW * WX_POS + WX_PLANE + ith.dst) = hlo;
+    const unsigned h = __builtin_bit_cast(unsigned short, hhi), l = __builtin_bit_cast(unsigned short, hlo), ad = st_halo;
+    asm volatile("ds_write_b16 %0, %1 offset:%3\n\tds_write_b16 %0, %2 offset:%4" ::"v"(ad), "v"(h), "v"(l), "n"(JW * WX_POS),
+                 "n"(JW * WX_POS + WX_PLANE)
+                 : "memory");
   };
 #define WX_I(n) std::integral_constant<int, n>{}
   // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB].
@@ -348,8 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   ldh(WX_I(0)); ldh(WX_I(1)); ldh(WX_I(2)); ldh(WX_I(3)); ldh(WX_I(4)); ldh(WX_I(5));
   ldsft();
   if constexpr (PRE >= 1) {
-    prM(WX_I(0)); prX(WX_I(0)); prM(WX_I(1)); prX(WX_I(1)); prM(WX_I(2)); prX(WX_I(2));
-    prM(WX_I(3)); prX(WX_I(3)); prM(WX_I(4)); prX(WX_I(4)); prM(WX_I(5)); prX(WX_I(5));
+    pr(WX_I(0)); pr(WX_I(1)); pr(WX_I(2)); pr(WX_I(3)); pr(WX_I(4)); pr(WX_I(5));
     prHa(); prHb();
   }
   pA(WX_I(0), WX_I(0)); pV(WX_I(0), WX_I(0)); pHi(WX_I(0)); pSub(WX_I(0)); pLo(WX_I(0)); pSt(WX_I(0), WX_I(0));
@@ -430,17 +429,17 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #undef WX_STAGE_CASE
     // end of stage: this wave's DMA pieces have landed (they are older than the pixel loads of stage 0, which stay in flight), its
     // LDS writes are done; then the workgroup barrier
-    // (last chunk: no pixel loads behind stage 0's pieces; stage 2 issued no piece, and the operand tile it requested stays in flight)
-    if constexpr (ji == 0 && !fin) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NPX) : "memory");
-    else if constexpr (ji == 2 && fin) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if constexpr (ji == 1 && fin) {
-      // a wait hipcc can SEE (the asm ones are opaque to it): a weight piece is a FLAT instruction that writes LDS, and while the
-      // compiler believes one is pending it turns every wait it inserts into vmcnt(0) -- here that would be the epilogue's first wait
-      // for its operand tile, with the next tile's requests already behind it
-      __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
-      asm volatile("s_barrier" ::: "memory");
-    }
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // The waits are the BUILTIN, which hipcc's wait-count pass can see (an asm one is opaque to it): a weight piece is a FLAT
+    // instruction that writes LDS, and while the compiler believes one is pending it turns every wait it inserts into vmcnt(0).
+    // Stage 0 leaves its NPX pixel loads in flight (the pieces are older); the last chunk has none, and its stage 2 issued no piece
+    // but requested the epilogue's operand tile, which stays in flight.
+    constexpr int WAIT_ALL = 0x0070;                                           // vmcnt(0) expcnt(7) lgkmcnt(0)
+    constexpr int WAIT_PX = (NPX & 15) | 0x0070 | ((NPX >> 4) << 14);          // vmcnt(NPX) lgkmcnt(0)
+    constexpr int WAIT_LDS = 0xC07F;                                           // lgkmcnt(0) only
+    if constexpr (ji == 0 && !fin) __builtin_amdgcn_s_waitcnt(WAIT_PX);
+    else if constexpr (ji == 2 && fin) __builtin_amdgcn_s_waitcnt(WAIT_LDS);
+    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    asm volatile("s_barrier" ::: "memory");
 #ifdef VIRNET_F16_TIMING
     wx_tg[ji][9] += (long long)__builtin_amdgcn_s_memtime() - wx_tprev;       // tail slot + waits + barrier
 #endif
