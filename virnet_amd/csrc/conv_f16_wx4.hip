@@ -303,7 +303,11 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB].
   // Waves without a piece in the last round move their previous piece again (same bytes to the same place): no branch.
   const size_t slab_bytes = (size_t)nch * WX_CHUNK_BYTES;
-  const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes + lane * 16;
+  // (a buffer descriptor over this channel block's NREP slabs: the piece's source offset is scalar, the lane offset a constant register --
+  // no per-piece 64-bit address arithmetic, and a MUBUF instruction, not a FLAT one)
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes), 0,
+                                                     (int)(NREP * slab_bytes), 0x00020000);
+  const int lane16 = lane * 16;
   int poff[NDI], pdst[NDI];
 #pragma unroll
   for (int i = 0; i < NDI; ++i) {
@@ -315,8 +319,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     pdst[i] = __builtin_amdgcn_readfirstlane(qd * 1024);
   }
   auto dma_piece = [&](int i, int src_off, char* wb) {      // src_off = chunk * 36 KB + ji * 6 KB
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wcb + src_off + poff[i]),
-                                     (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)                // (the host pass drops the kernel's stub without a diagnostic when it meets this builtin)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, lane16, src_off + poff[i], 0, 0);
+#endif
   };
 
   // ---- fragment addressing
