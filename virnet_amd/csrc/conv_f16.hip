@@ -124,16 +124,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 
   // ---- weight DMA: piece q = (tap-in-group, slab, hi|lo), 1 KB = the fragment of one MFMA operand; wave w moves pieces w, w+4, ...
   const size_t slab_bytes = (size_t)nch * 9 * 2048;
-  const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes + lane * 16;
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes), 0,
+                                                     (int)(NREP * slab_bytes), 0x00020000);
+  const int lane16w = lane * 16;
   auto dma_group = [&](int stage, char* wb) {
 #pragma unroll
     for (int i = 0; i < (NDMA + 3) / 4; ++i) {
       const int qd = BF ? 2 * (i * 4 + wave) : i * 4 + wave;        // (bf16 variant: the hi pieces only)
       if (qd < NDMA) {
         const int tg = qd / (NREP * 2), rem = qd - tg * (NREP * 2);
-        const char* src = wcb + (size_t)(rem >> 1) * slab_bytes + (size_t)((stage * 3 + tg) * 2 + (rem & 1)) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(wb + qd * 1024), 16, 0, 0);
+        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * 3 + tg) * 2 + (rem & 1)) * 1024);
       }
     }
   };

@@ -46,6 +46,17 @@ struct FArgs {
   int* range_flag;         // sticky device flag (virnet_set_range_flag) set when a staged operand leaves fp16's range, or NULL
 };
 
+// One 1-KB piece (64 lanes x 16 B) global -> LDS without a register round trip, as a MUBUF instruction (buffer_load_dwordx4 ... lds):
+// descriptor over the weight image, lane offset in a register, piece offset scalar.  Against global_load_lds (a FLAT instruction with a
+// 64-bit address per lane) it saves the per-piece address arithmetic, and hipcc's wait-count pass does not treat it as a pending FLAT
+// operation (which turns every wait it inserts into vmcnt(0): profiles/r03_probes.md).
+template <class Rsrc>
+__device__ __forceinline__ void lds_dma16(Rsrc rs, char* lds_dst, int lane_off, int piece_off) {
+#if defined(__HIP_DEVICE_COMPILE__)                // (the host pass drops a kernel's stub without a diagnostic when it meets this builtin)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, lane_off, piece_off, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
   const f32x4 t = u * s;
   return f32x4{fmaxf(u.x, t.x), fmaxf(u.y, t.y), fmaxf(u.z, t.z), fmaxf(u.w, t.w)};

@@ -94,16 +94,16 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
 
   // ---- weight DMA: piece = (tap-in-group, slab of the workgroup, hi|lo), 1 KB; wave w moves pieces w, w + NWAVES, ...
   const size_t slab_bytes = (size_t)nch * 9 * 2048;
-  const char* const wcb = a.wimg + (size_t)(a.slab_base + cb * SLABS) * slab_bytes + lane * 16;
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg + (size_t)(a.slab_base + cb * SLABS) * slab_bytes), 0,
+                                                     (int)(SLABS * slab_bytes), 0x00020000);
+  const int lane16w = lane * 16;
   auto dma_group = [&](int stage, char* wb) {
 #pragma unroll
     for (int i = 0; i < (NDMA + NWAVES - 1) / NWAVES; ++i) {
       const int qd = i * NWAVES + wv;
       if (qd < NDMA) {
         const int tg = qd / (SLABS * 2), rem = qd - tg * (SLABS * 2);
-        const char* src = wcb + (size_t)(rem >> 1) * slab_bytes + (size_t)((stage * 3 + tg) * 2 + (rem & 1)) * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(wb + qd * 1024), 16, 0, 0);
+        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * 3 + tg) * 2 + (rem & 1)) * 1024);
       }
     }
   };
