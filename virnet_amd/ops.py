@@ -114,7 +114,7 @@ def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     """The Winograd-along-x kernel works on 16 x 32 pixel tiles x 96 channels, one workgroup per CU: worth it when the image fills its
     tiles reasonably.  The rule looks at ONE image's shape only (never at the batch size): a network's result for an image must not
     depend on what else is in the batch (tests/test_e2e_gpu.py holds that bit for bit)."""
-    if cout < int(os.environ.get("VIRNET_WX4_MIN_COUT", "96")):          # (64 channels: two-slab workgroups re-stage the pixels for 18 MFMAs per stage; measured level with conv_f16)
+    if cout < int(os.environ.get("VIRNET_WX4_MIN_COUT", "64")):          # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
         return False
     th, tw = (h + 15) // 16, (w + 31) // 32
     fill = (h * w) / float(th * 16 * tw * 32)
