@@ -25,8 +25,8 @@ the stage's first piece).
 Usage: python tools/gen_wx4_sched.py > virnet_amd/csrc/conv_f16_wx4_sched.inc      (knobs: CAP, LDS_LAT below)"""
 import sys
 
-CAP = 5        # issue units per slot (an MFMA hides about five single-issue instructions)
-LDS_LAT = 3    # slots between a fragment read and the MFMA that consumes it
+CAP = int(__import__('os').environ.get('WX4_CAP', '5'))        # issue units per slot (an MFMA hides about five single-issue instructions)
+LDS_LAT = int(__import__('os').environ.get('WX4_LDS_LAT', '3'))    # slots between a fragment read and the MFMA that consumes it
 HEAD_CAP = 14  # slot 0 sits behind the barrier, in front of the first MFMA which waits for its fragments anyway
 S1_START = int(__import__("os").environ.get("WX4_S1_START", "8"))   # stage 1: first slot that touches the pixels requested in stage 0
 S1_START_PRE = int(__import__("os").environ.get("WX4_S1_START_PRE", "3"))   # ... when they are pre-activated first (more work to place)
