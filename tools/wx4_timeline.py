@@ -49,6 +49,9 @@ def main():
     nst = (c // 16)
     print(f"{len(st)} workgroups; per workgroup (median cycles): prologue {np.median(pro):.0f}, K loop {np.median(kl):.0f} "
           f"({np.median(kl) / (3 * nst):.0f} per stage), epilogue {np.median(ep):.0f}")
+    if st[:, 4].any():
+        print(f"prologue split (median cycles after the start stamp): requests issued {np.median(st[:, 4] - st[:, 0]):.0f}, all arrived + first position staged "
+              f"{np.median(st[:, 5] - st[:, 0]):.0f}, V written + barrier {np.median(pro):.0f}")
     if st[:, 6].any():
         print(f"epilogue split (median cycles after the K loop): first exchange written + barrier {np.median(st[:, 6] - st[:, 2]):.0f}, "
               f"slab 0 stored {np.median(st[:, 7] - st[:, 2]):.0f}, exit {np.median(ep):.0f}")
