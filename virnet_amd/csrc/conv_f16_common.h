@@ -39,6 +39,7 @@ struct FArgs {
   int NP, cout;            // NP: GEMM rows (output channels) covered by THIS launch, starting at slab `slab_base`
   int slab_base;
   int ntx, nty, ntiles, tiles_per_xcd;
+  unsigned mg_ncb, mg_ntx, mg_tpi;   // floor(2^32 / d) + 1 for d = channel blocks per tile, tiles per row, tiles per image (conv_wx4: fast_div)
   int in_act;
   int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
   float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
@@ -56,6 +57,12 @@ __device__ __forceinline__ void lds_dma16(Rsrc rs, char* lds_dst, int lane_off, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, lane_off, piece_off, 0, 0);
 #endif
 }
+
+// n / d for a launch-invariant d with the host's magic number m = floor(2^32 / d) + 1: exact while n * d < 2^32 (the launchers check).
+// A runtime division on the scalar unit is a reciprocal on the VECTOR unit and back (~150 cycles of latency each).
+// (d = 1 has no 32-bit magic number: 0 stands for it)
+__device__ __forceinline__ int fast_div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+inline unsigned div_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned long long)d) + 1u; }
 
 __device__ __forceinline__ f32x4 lrelu4(f32x4 u, float s) {
   const f32x4 t = u * s;

@@ -118,12 +118,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const int ncb = a.NP / NB;
   const int xcd = blockIdx.x & 7;
   const int q = blockIdx.x >> 3;
-  const int cb = __builtin_amdgcn_readfirstlane(q % ncb);
-  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + q / ncb);
-  if (q / ncb >= a.tiles_per_xcd || tile >= a.ntiles) return;
-  const int tx = __builtin_amdgcn_readfirstlane(tile % a.ntx);
-  const int ty = __builtin_amdgcn_readfirstlane((tile / a.ntx) % a.nty);
-  const int img = __builtin_amdgcn_readfirstlane(tile / (a.ntx * a.nty));
+  const int qt = fast_div(q, a.mg_ncb);             // (divisions by launch invariants through the host's magic numbers)
+  const int cb = __builtin_amdgcn_readfirstlane(q - qt * ncb);
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt);
+  if (qt >= a.tiles_per_xcd || tile >= a.ntiles) return;
+  const int img = __builtin_amdgcn_readfirstlane(fast_div(tile, a.mg_tpi));
+  const int trem = tile - img * (a.ntx * a.nty);
+  const int ty = __builtin_amdgcn_readfirstlane(fast_div(trem, a.mg_ntx));
+  const int tx = __builtin_amdgcn_readfirstlane(trem - ty * a.ntx);
   const int oy0 = ty * 16, ox0 = tx * 32;
 
   const int tid = threadIdx.x;
@@ -632,6 +634,11 @@ int launch_wx4(FArgs k, hipStream_t st) {
   k.tiles_per_xcd = (k.ntiles + 7) / 8;
   const int ncb = k.NP / (32 * NREP);
   const unsigned grid = (unsigned)(8 * k.tiles_per_xcd * ncb);
+  if ((unsigned long long)grid * (unsigned)ncb >= (1ull << 32) || (unsigned long long)k.ntiles * (unsigned)(k.ntx * k.nty) >= (1ull << 32))
+    return virnet::set_error("virnet_conv_wx4: %d tiles x %d channel blocks exceed the index arithmetic of one launch", k.ntiles, ncb);
+  k.mg_ncb = div_magic(ncb);
+  k.mg_ntx = div_magic(k.ntx);
+  k.mg_tpi = div_magic(k.ntx * k.nty);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, k);
   return virnet::check_launch("conv_wx4 launch");
 }
