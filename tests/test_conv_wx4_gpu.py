@@ -30,6 +30,7 @@ def _form(monkeypatch):
     monkeypatch.setenv("VIRNET_WX4_MIN_TILES", "0")      # every shape through the kernel under test, also the ones the shape rule
     monkeypatch.setenv("VIRNET_WX4_MIN_COUT", "0")       # would hand to conv_f16 (small images, 32 / 64 channels)
     monkeypatch.setenv("VIRNET_WX4_MIN_FILL", "0")
+    monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")
 
 
 class ops_timer:
@@ -243,6 +244,7 @@ def test_range_guard_reruns_the_forward_in_fp32(monkeypatch):
     monkeypatch.delenv("VIRNET_WX4_MIN_TILES", raising=False)
     monkeypatch.delenv("VIRNET_WX4_MIN_COUT", raising=False)
     monkeypatch.delenv("VIRNET_WX4_MIN_FILL", raising=False)
+    monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")        # (one 64 x 64 image: the launch-size rule would keep it off the Winograd form)
     cfg = dict(n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input", noise_avg=False)
     net = VIRAttResUNet(im_chn=3, sigma_chn=1, **cfg)
     net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}), strict=True)

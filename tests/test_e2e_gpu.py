@@ -97,16 +97,22 @@ def test_denoise_cbsd68_shape_vs_oracle(manifest):
     assert float((mu.cpu() - mu_ref).abs().max()) <= TIGHT and float((sigma.cpu() - sig_ref).abs().max()) <= TIGHT
 
 
-def test_full_size_properties(manifest):
+def test_full_size_properties(manifest, monkeypatch):
     """BASELINE configs[1] ([64,3,128,128]) through size-independent properties:
-    batch independence (each image's result equals its single-image result bit for bit -- no cross-sample op exists,
-    SURVEY.md 8e), determinism, and translation of the batch order."""
+    batch independence (each image's result equals its single-image result -- no cross-sample op exists, SURVEY.md 8e: bit for bit
+    when the kernel form does not depend on the launch size, to fp32 noise under the default rule, which hands single small images to
+    the direct kernel: ops.wx4_shape_ok), determinism, and translation of the batch order."""
     net, _, _, _ = get_net(manifest, "syn")
     x = synth_images(64, 3, 128, 128).cuda()
     with torch.no_grad():
+        mu_auto, sigma_auto = net(x)
+        for i in (0, 17, 63):
+            mi, si = net(x[i:i + 1].contiguous())
+            assert float((mi[0] - mu_auto[i]).abs().max()) <= TIGHT and float((si[0] - sigma_auto[i]).abs().max()) <= TIGHT
+        monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")
         mu, sigma = net(x)
         mu2, _ = net(x)
-        assert torch.equal(mu, mu2)
+        assert torch.equal(mu, mu2) and torch.equal(mu, mu_auto)
         for i in (0, 17, 63):
             mi, si = net(x[i:i + 1].contiguous())
             assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
@@ -116,7 +122,7 @@ def test_full_size_properties(manifest):
     assert torch.isfinite(mu).all() and float(sigma.min()) >= 1e-10 and float(sigma.max()) <= 1e2 * (1 + 1e-6)
 
 
-def test_metric_shape_properties_256(manifest):
+def test_metric_shape_properties_256(manifest):  # noqa: C901
     """BASELINE configs[2]'s per-GPU shard -- the shape bench.py times: [32,3,256,256] through the denoise-syn net.  Size-independent
     properties: determinism, batch independence (bit for bit: no cross-sample op), batch-order permutation, output
     ranges; and the three convolution forms (split-fp16 default, Winograd, fp32 direct) agree at this size where the large-grid
@@ -125,12 +131,20 @@ def test_metric_shape_properties_256(manifest):
     net, _, _, _ = get_net(manifest, "syn")
     x = synth_images(32, 3, 256, 256).cuda()
     with torch.no_grad():
-        mu, sigma = net(x)
-        mu2, sigma2 = net(x)
-        assert torch.equal(mu, mu2) and torch.equal(sigma, sigma2)
-        for i in (0, 13, 31):
+        mu_auto, sigma_auto = net(x)
+        for i in (0, 13, 31):                        # default rule: single images run the direct kernel -> fp32 noise, not bits
             mi, si = net(x[i:i + 1].contiguous())
-            assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
+            assert float((mi[0] - mu_auto[i]).abs().max()) <= TIGHT and float((si[0] - sigma_auto[i]).abs().max()) <= TIGHT
+        os.environ["VIRNET_WX4_MIN_WGS"] = "0"       # form independent of the launch size: bit for bit
+        try:
+            mu, sigma = net(x)
+            mu2, sigma2 = net(x)
+            assert torch.equal(mu, mu2) and torch.equal(sigma, sigma2) and torch.equal(mu, mu_auto)
+            for i in (0, 13, 31):
+                mi, si = net(x[i:i + 1].contiguous())
+                assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
+        finally:
+            os.environ.pop("VIRNET_WX4_MIN_WGS", None)
         perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
         mup, _ = net(x[perm].contiguous())
         assert torch.equal(mup, mu[perm])
@@ -153,6 +167,7 @@ def test_metric_shape_properties_256(manifest):
 def test_denoise_vs_oracle_256_pair(manifest, monkeypatch, form):
     """The metric's image size against the CPU oracle at a batch it finishes in seconds: [2,3,256,256]."""
     monkeypatch.setenv("VIRNET_CONV_FORM", form)
+    monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")        # (two images do not fill the chip: the default rule would mix the forms)
     net, sd, cfg, _ = get_net(manifest, "syn")
     x = synth_images(2, 3, 256, 256)
     kw = {k: v for k, v in cfg.items() if k not in ("im_chn", "sigma_chn")}

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 os.environ["VIRNET_WX4_MIN_TILES"] = "0"
 os.environ["VIRNET_WX4_MIN_COUT"] = "0"
 os.environ["VIRNET_WX4_MIN_FILL"] = "0"
+os.environ["VIRNET_WX4_MIN_WGS"] = "0"
 from virnet_amd import ops  # noqa: E402
 from test_ops_gpu import make_conv, nchw, nhwc, rnd  # noqa: E402
 

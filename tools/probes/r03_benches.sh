@@ -16,3 +16,5 @@ try:
 except Exception as e: print("$f FAILED", e)
 PY
 done
+{ echo "# wx4 (default)"; python tools/bench_latency.py; python tools/bench_latency.py --graph; echo "# VIRNET_CONV_FORM=f16x3 (round 2's kernels)"; VIRNET_CONV_FORM=f16x3 python tools/bench_latency.py; } 2>/dev/null | grep -v amdgpu > gpurun_out/r03_latency.txt
+cat gpurun_out/r03_latency.txt
