@@ -113,7 +113,7 @@ def _f16_family() -> bool:
 def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     """The Winograd-along-x kernel works on 16 x 32 pixel tiles x 96 channels, ONE workgroup per CU, and a tile takes 2-3x as long as a
     tile of the direct kernel: worth it when the image fills its tiles reasonably AND the launch fills the chip (workgroups =
-    images x tiles x channel blocks >= VIRNET_WX4_MIN_WGS, default 256 = the CUs of an MI355X) -- single small images stay on the
+    images x tiles x channel blocks >= VIRNET_WX4_MIN_WGS, default 128 = half the CUs of an MI355X: measured break-even, tools/bench_conv.py --ab VIRNET_WX4_MIN_WGS=0,100000) -- single small images stay on the
     direct split-fp16 kernel, whose small-grid tile forms give the lower latency (tools/bench_latency.py).  The two forms agree to
     fp32 noise (<= 2e-5 on the network outputs), not bit for bit: with the default rule an image's result can differ in the last bits
     between batch sizes; VIRNET_WX4_MIN_WGS=0 (or a pinned VIRNET_CONV_FORM=f16x3) restores bitwise batch independence
@@ -124,7 +124,7 @@ def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     fill = (h * w) / float(th * 16 * tw * 32)
     if th * tw < int(os.environ.get("VIRNET_WX4_MIN_TILES", "1")) or fill < float(os.environ.get("VIRNET_WX4_MIN_FILL", "0.6")):
         return False
-    return n * th * tw * ((cout + 95) // 96) >= int(os.environ.get("VIRNET_WX4_MIN_WGS", "256"))
+    return n * th * tw * ((cout + 95) // 96) >= int(os.environ.get("VIRNET_WX4_MIN_WGS", "128"))
 
 
 def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
