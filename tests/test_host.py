@@ -107,3 +107,17 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libvirnet_hip.so")
     with pytest.raises(_native.NativeLibraryError, match="no CPU fallback"):
         _native.load()
+
+
+def test_wx4_shape_rule(monkeypatch):
+    """Which launches take the Winograd-along-x kernel (ops.wx4_shape_ok): enough output channels, tiles reasonably filled, and a launch
+    that fills the chip -- the headline batch on every level, a single 256 x 256 image only on the level where the two kernels are level."""
+    for k in ("VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS"):
+        monkeypatch.delenv(k, raising=False)
+    assert all(ops.wx4_shape_ok(32, s, s, c) for s, c in ((256, 96), (128, 192), (64, 288), (256, 64)))      # bench shape: all levels + SNet
+    assert ops.wx4_shape_ok(64, 32, 32, 288) and ops.wx4_shape_ok(16, 64, 64, 224)                            # configs[1] level 2, SISR level 2
+    assert ops.wx4_shape_ok(1, 256, 256, 96) and not ops.wx4_shape_ok(1, 128, 128, 192) and not ops.wx4_shape_ok(1, 64, 64, 288)
+    assert not ops.wx4_shape_ok(32, 256, 256, 32)                                                             # thin layers stay on conv_f16
+    assert not ops.wx4_shape_ok(64, 17, 33, 96)                                                               # 2 x 2 tiles for 561 pixels: fill 0.27
+    monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")                                                             # form independent of the launch size
+    assert ops.wx4_shape_ok(1, 128, 128, 192) and ops.wx4_shape_ok(1, 16, 32, 64)
