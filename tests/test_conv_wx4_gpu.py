@@ -153,10 +153,11 @@ def test_wx4_dgrad_packing_and_backward_epilogue():
 def test_wx4_randomised_sweep_against_direct_kernel(monkeypatch):
     """Seeded sweep over shapes / channel mixes / epilogue options: catches ordering bugs (plane reuse, partial tiles, odd chunk counts,
     the last chunk's self-refetch) -- the kernel must agree with the fp32 direct kernel run on the same tensors."""
-    g = np.random.Generator(np.random.Philox(key=[78, 4]))
+    import os
+    g = np.random.Generator(np.random.Philox(key=[78, int(os.environ.get("VIRNET_TEST_SWEEP_KEY", "4"))]))
     chans = [32, 48, 64, 96, 128, 160, 192, 224, 288]
     worst = 0.0
-    for case in range(36):
+    for case in range(int(os.environ.get("VIRNET_TEST_SWEEP_CASES", "36"))):     # (a longer one-off sweep: set the two variables)
         cin, cout = int(g.choice(chans)), int(g.choice([c for c in chans if c % 32 == 0]))
         n, h, w = int(g.integers(1, 4)), int(g.integers(1, 41)), int(g.integers(1, 75))
         opts = dict(pre=bool(g.integers(0, 2)), res=bool(g.integers(0, 2)), mask=bool(g.integers(0, 2)), sft=bool(g.integers(0, 3) == 0),
