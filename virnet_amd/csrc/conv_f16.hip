@@ -21,7 +21,7 @@
 //               global -> registers (fp32), pre-activated (AttResUNet.py:54-55: lrelu(x*mul+add), zero outside the image AFTER it),
 //               split and written to the other buffer one third per tap group.
 //   W (weights): pre-split, pre-scaled, packed as the exact LDS image [tap][slab][hi|lo][lane][16 B]; streamed global -> LDS by
-//               DMA (global_load_lds_dwordx4), three taps (one kernel column) per stage, double buffered.
+//               DMA (buffer_load_dwordx4 ... lds, conv_f16_common.h: lds_dma16), three taps (one kernel column) per stage, double buffered.
 //   Taps run column by column (dx outer): the MREP+2 input rows a wave needs for one dx are read ONCE and serve all three dy.
 // One barrier per tap group (54 MFMAs per wave at 2x3 blocks); two workgroups per CU cover each other's barriers and epilogues.
 // Epilogue: inverse scale, bias, mask, residual, activation as conv_mfma.hip, after a per-wave LDS turn-around of each 32-channel slab

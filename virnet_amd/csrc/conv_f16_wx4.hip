@@ -23,7 +23,7 @@
 //       ji = 0,1,2 in which every wave works on position 3jt + ji, so planes {ji, 3+ji} are dead after stage ji and the threads write
 //       the NEXT chunk's values into them during the following stage (raw pixels are held in registers across the three stages).
 //   U (LDS, 2 x 12*NREP KB): stage = positions {ji, 3+ji} x 3 row taps x NREP slabs x (hi|lo) fragments of 1 KB, streamed by DMA
-//       (global_load_lds_dwordx4) one stage ahead, double buffered; one barrier per stage (9*NREP MFMAs per wave).
+//       (buffer_load_dwordx4 ... lds: MUBUF, scalar piece offset) one stage ahead, double buffered; one barrier per stage (9*NREP MFMAs per wave).
 //   Staging: thread = (V row 0..15, x-tile, channel quad): 6 pixels x 4 channels -> 6 positions x 4 channels; the tile's two halo rows
 //       (V rows 16, 17) are 512 values per position pair = ONE extra scalar value per thread and stage.  All of it -- pixel loads,
 //       pre-activation, rows of B^T, the exact hi/lo split, LDS stores, the DMA pieces, the fragment reads -- is cut into
