@@ -293,6 +293,12 @@ int virnet_ca_gate(const float* x, const float* w1, const float* b1, const float
 /* RB_Layer tail (KNet.py:26,38): out = hcv * gate[n][c] + skip, all NHWC [n][h][w][c], c % 4 == 0. */
 int virnet_scale_add(const float* hcv, const float* gate, const float* skip, float* out, int n, int hw, int c, void* stream);
 
+/* CALayer + RB_Layer tail in one launch (KNet.py:15-26,38): out = hcv * sigmoid(W2 lrelu0.2(W1 mean_hw(hcv) + b1) + b2) + skip, for
+ * maps of at most 16384 float4 items per image (h*w*c/4; KernelNet's 16x16x64 map has 4096): one workgroup holds an image in
+ * registers.  Same arguments and limits as virnet_ca_gate / virnet_scale_add, which remain for larger maps. */
+int virnet_ca_scale_add(const float* hcv, const float* w1, const float* b1, const float* w2, const float* b2, const float* skip,
+                        float* out, int n, int h, int w, int c, int cr, void* stream);
+
 /* AttLayer weights (AttResUNet.py:18-25), all 1x1 convs stored [cout][cin]. */
 typedef struct virnet_sft_weights {
   const float *w1, *b1;   /* [nf1][e]   */

@@ -212,6 +212,12 @@ def test_knet_pieces():
     gate = ops.ca_gate(nhwc(h), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda())
     got = ops.scale_add(nhwc(h), gate, nhwc(skip))
     assert maxerr(nchw(got), ref_rb) <= 1e-6
+    fused = ops.ca_scale_add(nhwc(h), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), nhwc(skip))       # the one-launch form of the same
+    assert maxerr(nchw(fused), ref_rb) <= 1e-6
+    for (hh, ww) in ((16, 16), (31, 33), (64, 64), (65, 64)):                                       # 4 / 16 items per thread; 64 x 64 and larger: over the limit -> gate + scale launches
+        hb, sb = rnd(3, 64, hh, ww, seed=31), rnd(3, 64, hh, ww, seed=32)
+        ref_b = cpu_ref.ca_layer(sd, "ca.", hb) + sb
+        assert maxerr(nchw(ops.ca_scale_add(nhwc(hb), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), nhwc(sb))), ref_b) <= 1e-6, (hh, ww)
     t = rnd(3, 3, 7, 9, seed=29, lo=-12, hi=3)
     m = t.mean(dim=(2, 3))
     refk = torch.cat([torch.exp(torch.clamp(m[:, :2], min=cpu_ref.K_LOG_MIN, max=cpu_ref.K_LOG_MAX)), torch.tanh(m[:, 2:])], 1)

@@ -129,6 +129,7 @@ SYMBOLS = [
     ("virnet_ca_gate", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_scale_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_ca_scale_add", C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]),
     ("virnet_sft_vec", C.c_int, [C.c_void_p, C.POINTER(SftWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("virnet_sft_apply", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(SftWeights), C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_void_p]),

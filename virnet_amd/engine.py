@@ -84,8 +84,7 @@ def knet_forward(knet, x: Tensor) -> Tensor:
         _, a = ops.conv_mfma(cur, rb.body["0"].packed(), want_raw=False, want_act=True, slope=0.2)   # KNet.py:32-33
         hcv, _ = ops.conv_mfma(a, rb.body["2"].packed(), want_raw=True)                               # KNet.py:34
         ca = rb.body["3"].body
-        gate = ops.ca_gate(hcv, ca["0"].weight, ca["0"].bias, ca["2"].weight, ca["2"].bias)          # KNet.py:15-25
-        cur = ops.scale_add(hcv, gate, cur)                                                           # KNet.py:26,38
+        cur = ops.ca_scale_add(hcv, ca["0"].weight, ca["0"].bias, ca["2"].weight, ca["2"].bias, cur)  # KNet.py:15-26,38 (one launch)
     oh, ow = cur.shape[1:3]
     raw = _conv_planar(cur, knet.tail["0"], (oh, ow))                                                 # KNet.py:49
     return ops.gap_nchw(raw, ops.GAP_KINFO, (K_LOG_MIN, LOG_MAX)).view(n, -1, 1, 1)                  # KNet.py:50,56-59

@@ -543,6 +543,25 @@ def ca_gate(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor
     return gate
 
 
+CA_FUSED_MAX_ITEMS = 16 * 1024      # float4 items of one image the fused CALayer kernel holds in a workgroup's registers
+
+
+def ca_scale_add(hcv: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, skip: Tensor) -> Tensor:
+    """RB_Layer tail (KNet.py:15-26,38): hcv * CALayer gate(hcv) + skip on NHWC tensors -- one launch for small maps (KernelNet's
+    16 x 16 x 64), the gate + scale pair otherwise."""
+    _dev_check(hcv, "hcv"); _dev_check(skip, "skip")
+    n, h, w, c = hcv.shape
+    if h * w * (c // 4) > CA_FUSED_MAX_ITEMS or c % 4 or 256 % c:
+        return scale_add(hcv, ca_gate(hcv, w1, b1, w2, b2), skip)
+    ts = [t.detach() for t in (w1, b1, w2, b2)]
+    for t in ts:
+        _dev_check(t, "CALayer parameter")
+    out = torch.empty_like(hcv)
+    nat.check(nat.load().virnet_ca_scale_add(nat.ptr(hcv), *(nat.ptr(t) for t in ts), nat.ptr(skip), nat.ptr(out), n, h, w, c, w1.shape[0],
+                                             nat.stream_handle()), "ca_scale_add")
+    return out
+
+
 def scale_add(hcv: Tensor, gate: Tensor, skip: Tensor) -> Tensor:
     """hcv * gate[n,c] + skip on NHWC tensors."""
     _dev_check(hcv, "hcv"); _dev_check(skip, "skip"); _dev_check(gate, "gate")
