@@ -389,8 +389,11 @@ extern "C" int virnet_conv_head_s4(const float* x, const float* w, float* out, i
   }
   const int oh = (h - 1) / 4 + 1, ow = (w_ - 1) / 4 + 1;
   const long npix = (long)n * oh * ow;
-  int ppb = 32;
-  while ((npix + ppb - 1) / ppb > 2048) ppb *= 2;
+  // 4 pixels per block (one per pixel slot) while the grid stays moderate: a block walks its pixels one after the other, 243 dependent
+  // taps each, so 32 pixels per block left a single 64 x 64 image to 8 blocks and 130 us (the weight tile is re-staged per block from L2:
+  // 62 KB, cheap next to that)
+  int ppb = 4;
+  while ((npix + ppb - 1) / ppb > 4096) ppb *= 2;
   const int gx = (int)((npix + ppb - 1) / ppb);
   hipLaunchKernelGGL(conv_head_s4_kernel, dim3(gx, cout / 64), dim3(256), lds, static_cast<hipStream_t>(stream), x, w, out, n,
                      cin, h, w_, cout, oh, ow, ppb);
