@@ -176,6 +176,11 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+_stream_cache = None     # set by ops.forward_scope for the duration of one inference forward (the current stream does not change inside it)
+
+
 def stream_handle() -> int:
     """hipStream_t of torch's current stream, as the void* the C ABI takes."""
+    if _stream_cache is not None:
+        return _stream_cache
     return torch.cuda.current_stream().cuda_stream

@@ -178,15 +178,17 @@ def _range_guarded(run, x: Tensor):
     import warnings
     guarded = ops._f16_family() and ops.range_guard_enabled() and not torch.cuda.is_current_stream_capturing()
     if guarded:
-        ops.range_flag(x.device)
-    out = run()
+        ops.range_flag(x.device).zero_()     # (the flag is sticky: whatever raised it before this forward is not this forward's business)
+    with ops.forward_scope():                # (environment knobs and the stream handle: read once per forward, not per launch)
+        out = run()
     if guarded and ops.range_overflowed(x.device):
         warnings.warn("VIRNet HIP path: an activation left fp16's range in a split-fp16 convolution (|x| >= 65504, or >= ~6.5e3 in the "
                       "Winograd form); the forward was repeated with the fp32 kernels", RuntimeWarning, stacklevel=3)
         old = os.environ.get("VIRNET_CONV_FORM")
         os.environ["VIRNET_CONV_FORM"] = "wino"
         try:
-            out = run()
+            with ops.forward_scope():
+                out = run()
         finally:
             if old is None:
                 os.environ.pop("VIRNET_CONV_FORM", None)

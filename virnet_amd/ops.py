@@ -95,11 +95,42 @@ WINO_MIN_CHANNELS = 32
 DEFAULT_CONV_FORM = "wx4"
 
 
+# ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
+# the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
+_KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
+          "VIRNET_RANGE_GUARD")
+_scope_env = None
+
+
+class forward_scope:
+    """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
+    inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on)."""
+
+    def __enter__(self):
+        global _scope_env
+        self._prev = (_scope_env, nat._stream_cache)
+        _scope_env = {k: os.environ.get(k) for k in _KNOBS}
+        nat._stream_cache = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        return self
+
+    def __exit__(self, *exc):
+        global _scope_env
+        _scope_env, nat._stream_cache = self._prev
+        return False
+
+
+def _env(name: str, default=None):
+    if _scope_env is not None:
+        v = _scope_env.get(name)
+        return default if v is None else v
+    return os.environ.get(name, default)
+
+
 def conv_form() -> str:
     import os
-    form = os.environ.get("VIRNET_CONV_FORM")
+    form = _env("VIRNET_CONV_FORM")
     if form is None:
-        legacy = os.environ.get("VIRNET_WINOGRAD")
+        legacy = _env("VIRNET_WINOGRAD")
         form = DEFAULT_CONV_FORM if legacy is None else ("direct" if legacy == "0" else "wino")
     if form not in ("f16x3", "wino", "direct", "bf16", "wx4"):
         raise ValueError(f"VIRNET_CONV_FORM={form!r}: expected wx4, f16x3, wino, direct or bf16")
@@ -118,13 +149,13 @@ def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     fp32 noise (<= 2e-5 on the network outputs), not bit for bit: with the default rule an image's result can differ in the last bits
     between batch sizes; VIRNET_WX4_MIN_WGS=0 (or a pinned VIRNET_CONV_FORM=f16x3) restores bitwise batch independence
     (tests/test_e2e_gpu.py holds both)."""
-    if cout < int(os.environ.get("VIRNET_WX4_MIN_COUT", "64")):          # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
+    if cout < int(_env("VIRNET_WX4_MIN_COUT", "64")):          # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
         return False
     th, tw = (h + 15) // 16, (w + 31) // 32
     fill = (h * w) / float(th * 16 * tw * 32)
-    if th * tw < int(os.environ.get("VIRNET_WX4_MIN_TILES", "1")) or fill < float(os.environ.get("VIRNET_WX4_MIN_FILL", "0.6")):
+    if th * tw < int(_env("VIRNET_WX4_MIN_TILES", "1")) or fill < float(_env("VIRNET_WX4_MIN_FILL", "0.6")):
         return False
-    return n * th * tw * ((cout + 95) // 96) >= int(os.environ.get("VIRNET_WX4_MIN_WGS", "128"))
+    return n * th * tw * ((cout + 95) // 96) >= int(_env("VIRNET_WX4_MIN_WGS", "128"))
 
 
 def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
@@ -156,7 +187,7 @@ _RANGE_FLAGS: dict = {}
 
 
 def range_guard_enabled() -> bool:
-    return os.environ.get("VIRNET_RANGE_GUARD", "1") != "0"
+    return _env("VIRNET_RANGE_GUARD", "1") != "0"
 
 
 def range_flag(device: torch.device) -> Optional[Tensor]:
