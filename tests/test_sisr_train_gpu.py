@@ -68,6 +68,30 @@ def test_sisr_gradients_match_autograd_oracle(cfg, shape, sf):
     assert float(np.mean(errs > 1e-4)) <= 0.34 and float(np.median(errs)) <= 1e-4, (float(np.mean(errs > 1e-4)), float(np.median(errs)))
 
 
+@pytest.mark.parametrize("factor", [1e6, 1e-7])
+def test_sisr_backward_does_not_depend_on_the_loss_scale(factor):
+    """The SISR step's backward rescales the three incoming gradients by one power of two at the network boundary and scales every
+    parameter gradient back (train_sisr._Boundary): the gradients of `factor * loss` are factor times those of `loss`, for a factor that
+    would flush the split-fp16 GEMMs' operands to zero and for one that would overflow them."""
+    net, _ = build(SMALL)
+    x = synth_images(2, 3, 12, 20).cuda()
+    gt = synth_images(2, 3, 24, 40, seed=2).cuda()
+
+    def grads(f):
+        for p in net.parameters():
+            p.grad = None
+        mu, kinfo, sigma = net(x, 2)
+        (surrogate_loss(mu, kinfo, sigma, gt) * f).backward()
+        return {k: p.grad.double().clone() for k, p in net.named_parameters()}
+
+    base, scaled = grads(1.0), grads(factor)
+    assert net._sisr_grad_scale.scale != 1.0
+    for k in base:
+        ref, got = base[k], scaled[k] / factor
+        assert bool(torch.isfinite(got).all()), k
+        assert float((got - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1e-30), (k, factor)
+
+
 def test_sisr_training_loop_shape():
     """train_SISR.py:207-224: elbo_sisr on the three outputs, backward, per-sub-network gradient clipping, Adam; the loss goes down
     and the packed weights follow the parameter updates (next forward differs)."""

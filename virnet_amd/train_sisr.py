@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -304,6 +306,47 @@ def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# loss-scale independence of the backward.  Every GEMM of the backward splits its operands into fp16 pairs, exact between 6e-5 and
+# 65504; a mean-reduced loss hands over ~1e-7 per entry, a sum-reduced one or a GradScaler 1e4 and more.  The backward is linear, so the
+# three incoming gradients are multiplied by ONE power of two at the network's boundary (this node sees them together) and every
+# parameter gradient is divided by it again where it leaves the graph (a hook on the leaf).  The factor is 1 -- and the hooks do
+# nothing -- while the largest incoming entry lies in [2^-10, 2^10]; deciding that costs one device -> host read per backward.
+# ----------------------------------------------------------------------------------------------------------------------
+class _GradScaleState:
+    def __init__(self):
+        self.scale = 1.0
+
+
+class _Boundary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, kinfo, sigma, state):
+        ctx.state = state
+        return mu.view_as(mu), kinfo.view_as(kinfo), sigma.view_as(sigma)
+
+    @staticmethod
+    def backward(ctx, dmu, dkinfo, dsigma):
+        grads = [g for g in (dmu, dkinfo, dsigma) if g is not None]
+        amax = max(float(g.detach().abs().amax()) for g in grads) if grads else 0.0
+        scale = 1.0
+        if amax > 0.0 and math.isfinite(amax) and not (2.0 ** -10 <= amax <= 2.0 ** 10):
+            scale = 2.0 ** (-math.floor(math.log2(amax)) - 1)          # largest entry -> [0.5, 1)
+        ctx.state.scale = scale
+        if scale == 1.0:
+            return dmu, dkinfo, dsigma, None
+        return tuple(None if g is None else g * scale for g in (dmu, dkinfo, dsigma)) + (None,)
+
+
+def _install_unscale_hooks(net) -> _GradScaleState:
+    state = getattr(net, "_sisr_grad_scale", None)
+    if state is None:
+        state = _GradScaleState()
+        for p in net.parameters():
+            p.register_hook(lambda g, st=state: g if st.scale == 1.0 else g * (1.0 / st.scale))   # (a power of two: exact)
+        net._sisr_grad_scale = state
+    return state
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # boundary forward (networks/VIRNet.py:80-97) with gradients
 # ----------------------------------------------------------------------------------------------------------------------
 def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
@@ -328,4 +371,4 @@ def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
             parts.append(sigma.view(n, -1).sqrt())                                            # VIRNet.py:92
         vec = torch.cat(parts, 1) if parts else None
         mu = _rnet(net.RNet, x, vec, sf)
-    return mu, kinfo, sigma
+    return _Boundary.apply(mu, kinfo, sigma, _install_unscale_hooks(net))
