@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
@@ -176,11 +177,12 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-_stream_cache = None     # set by ops.forward_scope for the duration of one inference forward (the current stream does not change inside it)
+tls = threading.local()  # ops.forward_scope keeps its per-forward snapshot here (stream handle, environment knobs): one per host thread
 
 
 def stream_handle() -> int:
     """hipStream_t of torch's current stream, as the void* the C ABI takes."""
-    if _stream_cache is not None:
-        return _stream_cache
+    cached = getattr(tls, "stream_cache", None)
+    if cached is not None:
+        return cached
     return torch.cuda.current_stream().cuda_stream

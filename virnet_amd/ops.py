@@ -99,29 +99,27 @@ DEFAULT_CONV_FORM = "wx4"
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
           "VIRNET_RANGE_GUARD")
-_scope_env = None
-
-
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
-    inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on)."""
+    inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The
+    snapshot is per THREAD (nat.tls): forwards running in several host threads, each on its own stream, do not see each other's."""
 
     def __enter__(self):
-        global _scope_env
-        self._prev = (_scope_env, nat._stream_cache)
-        _scope_env = {k: os.environ.get(k) for k in _KNOBS}
-        nat._stream_cache = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
+        tls = nat.tls
+        self._prev = (getattr(tls, "scope_env", None), getattr(tls, "stream_cache", None))
+        tls.scope_env = {k: os.environ.get(k) for k in _KNOBS}
+        tls.stream_cache = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         return self
 
     def __exit__(self, *exc):
-        global _scope_env
-        _scope_env, nat._stream_cache = self._prev
+        nat.tls.scope_env, nat.tls.stream_cache = self._prev
         return False
 
 
 def _env(name: str, default=None):
-    if _scope_env is not None:
-        v = _scope_env.get(name)
+    snap = getattr(nat.tls, "scope_env", None)
+    if snap is not None:
+        v = snap.get(name)
         return default if v is None else v
     return os.environ.get(name, default)
 

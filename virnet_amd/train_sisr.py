@@ -316,6 +316,9 @@ class _GradScaleState:
     def __init__(self):
         self.scale = 1.0
 
+    def __deepcopy__(self, memo):      # the parameter hooks of a copied module still point at THIS object: the copy must share it
+        return self
+
 
 class _Boundary(torch.autograd.Function):
     @staticmethod
