@@ -23,8 +23,11 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(autouse=True)
-def _form(monkeypatch):
+@pytest.fixture(autouse=True, params=[16, 8], ids=["rows16", "rows8"])
+def _form(monkeypatch, request):
+    # both tile forms of the kernel: 16-row tiles / 8 waves (conv_f16_wx4.hip) and 8-row tiles / 4 waves / weight ring (conv_f16_wx4h.hip);
+    # the library picks one per launch size otherwise (virnet_conv_wx4)
+    monkeypatch.setenv("VIRNET_WX4_ROWS", str(request.param))
     monkeypatch.delenv("VIRNET_WINOGRAD", raising=False)
     monkeypatch.setenv("VIRNET_CONV_FORM", "wx4")
     monkeypatch.setenv("VIRNET_WX4_MIN_TILES", "0")      # every shape through the kernel under test, also the ones the shape rule

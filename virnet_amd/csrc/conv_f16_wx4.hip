@@ -32,7 +32,7 @@
 // Epilogue: the inverse transform crosses the two waves of a row block, so per 32-channel slab every wave writes three pre-combined
 // blocks ([pixel][channel] records) to LDS and each thread finishes (pixel, channel quad) items from two or three of them: the same
 // round trip also turns the tile around for 128-byte runs in the NHWC store.  Inverse scale, bias, mask, residual, activation as conv_f16.hip.
-#include "conv_f16_common.h"
+#include "conv_f16_wx4_common.h"
 #include "conv_f16_wx4_sched.inc"
 #include <cstdlib>
 #include <type_traits>
@@ -40,64 +40,12 @@
 namespace {
 using namespace virnet;
 
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
 constexpr int WX_PLANE = 18 * 8 * 32;        // one (position, hi|lo) plane: [18 rows][8 x-tiles][32 B]
 constexpr int WX_POS = 2 * WX_PLANE;
 constexpr int WX_VBYTES = 6 * WX_POS;        // 55296
 constexpr int WX_XBLK = 32 * 144 + 64;       // exchange block: [32 columns][32 channels + 16 B pad], skewed by 64 B against its neighbours
 constexpr int WX_CHUNK_BYTES = 36 * 1024;
 // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB] = WX_CHUNK_BYTES
-
-template <int J>
-__device__ __forceinline__ f32x4 wx4_pos(const f32x4 (&d)[6]) {
-  // rows of BT (Lavin & Gray, F(4,3), points 0, +-1, +-2, inf)
-  if constexpr (J == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
-  if constexpr (J == 1) return (d[4] - 4.f * d[2]) + (d[3] - 4.f * d[1]);
-  if constexpr (J == 2) return (d[4] - 4.f * d[2]) - (d[3] - 4.f * d[1]);
-  if constexpr (J == 3) return (d[4] - d[2]) + 2.f * (d[3] - d[1]);
-  if constexpr (J == 4) return (d[4] - d[2]) - 2.f * (d[3] - d[1]);
-  return 4.f * d[1] - 5.f * d[3] + d[5];
-}
-
-// max of two floats as the bare instruction: fmaxf() on a value that comes straight from a load first copies it through a
-// canonicalising v_max x, x (IEEE sNaN quieting), one VALU op per staged value
-__device__ __forceinline__ float vmax(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// two fp32 -> packed fp16x2, round to nearest even (v_cvt_pk_f16_f32)
-__device__ __forceinline__ unsigned cvtpk(float a, float b) {
-  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  const h2 r = {(_Float16)a, (_Float16)b};
-  return __builtin_bit_cast(unsigned, r);
-}
-// v - float(half HALF of hpk) in ONE VALU operation (v_fma_mix_f32 reads the fp16 half directly); exact like the subtraction
-template <int HALF>
-__device__ __forceinline__ float subhi(float v, unsigned hpk) {
-  float r;
-  if constexpr (HALF == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
-  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hpk), "v"(v));
-  return r;
-}
-
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. would wait for global loads in flight
-__device__ __forceinline__ void wx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct WxItem {
-  unsigned voff;     // byte offset of the item's first input pixel (row, 4*xtile - 1) from the image base; may wrap (the load is masked)
-  unsigned inb;      // bit b: pixel b lies inside the image
-  int dst;           // byte offset of this item inside a V plane
-};
-
-// BT rows as coefficient vectors (the halo rows are staged one value per thread: v = sum_b c[b] * d[b])
-__device__ __forceinline__ float wx4_coef(int j, int b) {
-  constexpr float BT[6][6] = {{4.f, 0.f, -5.f, 0.f, 1.f, 0.f}, {0.f, -4.f, -4.f, 1.f, 1.f, 0.f}, {0.f, 4.f, -4.f, -1.f, 1.f, 0.f},
-                              {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, 4.f, 0.f, -5.f, 0.f, 1.f}};
-  return BT[j][b];
-}
 
 // PRE: what the conv applies to x while it is staged -- 0: nothing; 1: lrelu(x, in_slope); 2: lrelu(x*in_mul+in_add, in_slope), the SFT
 // pre-activation of AttResUNet.py:54-55 with per-(image, channel) vectors.
@@ -301,7 +249,6 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
                  "n"(JW * WX_POS + WX_PLANE)
                  : "memory");
   };
-#define WX_I(n) std::integral_constant<int, n>{}
   // ---- weight DMA: piece q = i*8 + wave -> (jt, dy, slab, hi|lo) in LDS order; source = [slab][chunk][position][dy][hi|lo][1 KB].
   // Waves without a piece in the last round move their previous piece again (same bytes to the same place): no branch.
   const size_t slab_bytes = (size_t)nch * WX_CHUNK_BYTES;
@@ -746,11 +693,36 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
   int n3 = nb / 3, rem = nb - 3 * n3;
   if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
   const int n2 = rem / 2, n1 = rem - 2 * n2;
+  // Tile form per launch: 16-row tiles / 8 waves / one workgroup per CU (this file) or 8-row tiles / 4 waves / two per CU
+  // (conv_f16_wx4h.hip).  Measured (profiles/r04_probes.md): on launches that fill the chip many times over both forms run the socket
+  // at its 1400 W power cap and the 16-row form is 3-6 % ahead (fewer barriers and weight pieces per MFMA) -- except with two-slab
+  // workgroups (64 channels), where the 8-row form is 4 % ahead; on launches of a few hundred workgroups the 8-row form wins whenever
+  // its finer grain saves a round: a lone 8-row workgroup takes ~0.55 of a 16-row one, a co-resident pair ~1.04.
+  // VIRNET_WX4_ROWS=8|16 pins the form (A/B runs, tests).
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  const char* const rows_env = getenv("VIRNET_WX4_ROWS");
+  const int rows_pin = rows_env ? atoi(rows_env) : 0;
+  auto half_tiles_for = [&](int nrep, int groups) -> bool {
+    if (rows_pin == 8) return true;
+    if (rows_pin == 16) return false;
+    const long w16 = (long)d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * groups;
+    const long w8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32) * groups;
+    if (w16 >= 8L * n_cu) return nrep <= 2;                     // chip filled many times over
+    const double t16 = (double)((w16 + n_cu - 1) / n_cu);
+    const long full = w8 / (2L * n_cu), tail = w8 - full * 2L * n_cu;
+    const double t8 = 1.04 * (double)full + (tail == 0 ? 0.0 : tail <= n_cu ? 0.55 : 1.04);
+    return t8 < t16;
+  };
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
+    if (half_tiles_for(nrep, groups)) return virnet::launch_wx4h(kk, nrep, epi, pre, st);
 #define VIRNET_WX4_EPI(N_, E_)                                                                                               \
     if (epi == E_) return pre == 2 ? launch_wx4<N_, E_, 2>(kk, st) : pre == 1 ? launch_wx4<N_, E_, 1>(kk, st) : launch_wx4<N_, E_, 0>(kk, st);
 #define VIRNET_WX4_CASE(N_)                                                                              \
