@@ -172,6 +172,10 @@ int virnet_conv_wx4(const virnet_conv_desc* d, void* stream);
  * device (NULL = off); the kernels OR 1 into it when a staged operand leaves the range.  The host side (virnet_amd/engine.py) reads it at
  * the end of a forward and re-runs the image in the fp32 Winograd form.  The reference's fp32 path has no such limit. */
 int virnet_set_range_flag(int* device_flag);
+/* (the registration is per (device, calling host thread): forwards driven from several threads keep separate flags)
+ * virnet_poison_on_flag: fills y[0..n) with NaN when *device_flag != 0 -- the last node of a replayed hipGraph (virnet_amd/graph.py), so
+ * that an out-of-range forward is loud even before the host has read the flag. */
+int virnet_poison_on_flag(const int* device_flag, float* y, size_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 3x3 convolution to 1..4 output channels with planar store (HBM/LDS-bound VALU kernel, not MFMA work):

@@ -270,6 +270,29 @@ def test_range_guard_reruns_the_forward_in_fp32(monkeypatch):
         assert not bool(torch.isfinite(mu_raw).all())
 
 
+def test_tile_form_rule_runs_one_of_the_two_forms(monkeypatch):
+    """Without VIRNET_WX4_ROWS the library picks the tile height per launch size (csrc/conv_f16_wx4.hip: rounds of workgroups over the
+    CUs); whichever it picks, the result is bit for bit the pinned form's, and the rule's two regimes are both exercised."""
+    monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "1")          # ("0" is the deterministic switch: it pins the tile height as well)
+    c = 96
+    cp = make_conv(c, c, seed=21).cuda()
+    picked = {}
+    for name, (n, h, w) in {"one_small_image": (1, 64, 64), "one_round_of_16_row_tiles": (8, 128, 128)}.items():
+        x = nhwc(rnd(n, c, h, w, seed=22))
+        outs = {}
+        for rows in ("16", "8", None):
+            if rows is None:
+                monkeypatch.delenv("VIRNET_WX4_ROWS", raising=False)
+            else:
+                monkeypatch.setenv("VIRNET_WX4_ROWS", rows)
+            outs[rows], _ = ops.conv_mfma(x, cp.packed(), want_raw=True)
+        assert not torch.equal(outs["16"], outs["8"])          # (the halo rows are transformed with differently associated fp32 sums)
+        assert float((outs["16"] - outs["8"]).abs().max()) <= TOL
+        picked[name] = "8" if torch.equal(outs[None], outs["8"]) else "16"
+        assert torch.equal(outs[None], outs[picked[name]])
+    assert picked == {"one_small_image": "8", "one_round_of_16_row_tiles": "16"}, picked
+
+
 def test_wx4_abi_rejects_bad_descriptors():
     cp = make_conv(96, 96).cuda()
     pw = cp.packed()

@@ -109,10 +109,10 @@ def test_full_size_properties(manifest, monkeypatch):
         for i in (0, 17, 63):
             mi, si = net(x[i:i + 1].contiguous())
             assert float((mi[0] - mu_auto[i]).abs().max()) <= TIGHT and float((si[0] - sigma_auto[i]).abs().max()) <= TIGHT
-        monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")
+        monkeypatch.setenv("VIRNET_DETERMINISTIC", "1")       # one kernel form and tile height whatever the launch size
         mu, sigma = net(x)
         mu2, _ = net(x)
-        assert torch.equal(mu, mu2) and torch.equal(mu, mu_auto)
+        assert torch.equal(mu, mu2) and float((mu - mu_auto).abs().max()) <= TIGHT
         for i in (0, 17, 63):
             mi, si = net(x[i:i + 1].contiguous())
             assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
@@ -135,19 +135,19 @@ def test_metric_shape_properties_256(manifest):  # noqa: C901
         for i in (0, 13, 31):                        # default rule: single images run the direct kernel -> fp32 noise, not bits
             mi, si = net(x[i:i + 1].contiguous())
             assert float((mi[0] - mu_auto[i]).abs().max()) <= TIGHT and float((si[0] - sigma_auto[i]).abs().max()) <= TIGHT
-        os.environ["VIRNET_WX4_MIN_WGS"] = "0"       # form independent of the launch size: bit for bit
+        os.environ["VIRNET_DETERMINISTIC"] = "1"     # form and tile height independent of the launch size: bit for bit
         try:
             mu, sigma = net(x)
             mu2, sigma2 = net(x)
-            assert torch.equal(mu, mu2) and torch.equal(sigma, sigma2) and torch.equal(mu, mu_auto)
+            assert torch.equal(mu, mu2) and torch.equal(sigma, sigma2) and float((mu - mu_auto).abs().max()) <= TIGHT
             for i in (0, 13, 31):
                 mi, si = net(x[i:i + 1].contiguous())
                 assert torch.equal(mi[0], mu[i]) and torch.equal(si[0], sigma[i])
         finally:
-            os.environ.pop("VIRNET_WX4_MIN_WGS", None)
+            os.environ.pop("VIRNET_DETERMINISTIC", None)
         perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
         mup, _ = net(x[perm].contiguous())
-        assert torch.equal(mup, mu[perm])
+        assert torch.equal(mup, mu_auto[perm])       # (default rule again: same launch sizes, same forms)
         assert torch.isfinite(mu).all() and float(sigma.min()) >= 1e-10 and float(sigma.max()) <= 1e2 * (1 + 1e-6)
         old = os.environ.get("VIRNET_CONV_FORM")
         try:

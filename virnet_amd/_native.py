@@ -98,6 +98,7 @@ SYMBOLS = [
     ("virnet_pack_wx4_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv_wx4", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("virnet_set_range_flag", C.c_int, [C.c_void_p]),
+    ("virnet_poison_on_flag", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("virnet_pack_bf16_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv_bf16", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     ("virnet_f16_convt_weight_floats", C.c_size_t, [C.c_int, C.c_int]),

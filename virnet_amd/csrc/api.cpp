@@ -18,7 +18,9 @@ int set_error(const char* fmt, ...) {
   return 1;
 }
 
-static int* g_range_flag[64] = {nullptr};
+// (per host THREAD: forwards running in several threads, each on its own stream, keep separate flags -- engine.py registers one per
+// (device, thread) on first use)
+static thread_local int* g_range_flag[64] = {nullptr};
 
 int* range_flag_ptr() {
   int dev = 0;

@@ -704,8 +704,11 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
+  // VIRNET_DETERMINISTIC=1 (or the older VIRNET_WX4_MIN_WGS=0): results must not depend on the launch size -> one tile form for all.
   const char* const rows_env = getenv("VIRNET_WX4_ROWS");
-  const int rows_pin = rows_env ? atoi(rows_env) : 0;
+  const char* const det_env = getenv("VIRNET_DETERMINISTIC");
+  const char* const wgs_env = getenv("VIRNET_WX4_MIN_WGS");
+  const int rows_pin = rows_env ? atoi(rows_env) : ((det_env && det_env[0] == '1') || (wgs_env && wgs_env[0] == '0' && wgs_env[1] == 0)) ? 16 : 0;
   auto half_tiles_for = [&](int nrep, int groups) -> bool {
     if (rows_pin == 8) return true;
     if (rows_pin == 16) return false;

@@ -491,3 +491,21 @@ extern "C" int virnet_sft_apply(const float* raw, const float* rec, const virnet
                      static_cast<hipStream_t>(stream), raw, rec, *wt, act, n, h, w, step, chan0);
   return virnet::check_launch("sft_apply launch");
 }
+
+// ---- range guard, device side of a replayed graph: when the sticky flag is up, overwrite an output with NaN so that a forward whose
+// split-fp16 operands left fp16's range can never be mistaken for a result (the exp(clamp) / tanh heads would hide the Inf otherwise).
+namespace {
+__global__ void poison_on_flag_kernel(const int* __restrict__ flag, float* __restrict__ y, size_t n) {
+  if (*flag == 0) return;
+  const float nan = __builtin_nanf("");
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = nan;
+}
+}  // namespace
+
+extern "C" int virnet_poison_on_flag(const int* device_flag, float* y, size_t n, void* stream) {
+  VIRNET_REQUIRE(device_flag && y, "virnet_poison_on_flag: NULL pointer");
+  if (n == 0) return 0;
+  const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  hipLaunchKernelGGL(poison_on_flag_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), device_flag, y, n);
+  return virnet::check_launch("poison_on_flag launch");
+}

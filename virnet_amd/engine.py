@@ -169,12 +169,15 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
 # ----------------------------------------------------------------------------------------------------------------
 # boundary forwards (reference networks/VIRNet.py:42-46 and :80-97)
 # ----------------------------------------------------------------------------------------------------------------
+FP32_FORM = "wino"      # the form of the guard's re-run: Winograd / direct fp32 MFMA kernels, no range limit
+
+
 def _range_guarded(run, x: Tensor):
     """Run a forward in the default (split-fp16) forms; when a kernel reports an operand outside fp16's range (virnet_set_range_flag)
-    run it again with the fp32 kernels (VIRNET_CONV_FORM=wino: Winograd / direct fp32 MFMA, no range limit) and return that result.
-    The check reads one int from the device, i.e. it waits for the forward; it is skipped while a hipGraph is being captured, for
-    the fp32 forms and with VIRNET_RANGE_GUARD=0."""
-    import os
+    run it again with the fp32 kernels and return that result.  The check reads one int from the device, i.e. it waits for the forward
+    (the caller is about to consume the outputs anyway); it is skipped while a hipGraph is being captured -- graph.GraphedForward does
+    its own check around the replay -- for the fp32 forms and with VIRNET_RANGE_GUARD=0.  The flag is per (device, host thread) and the
+    re-run's form override lives in the thread's forward_scope: nothing process-global is touched."""
     import warnings
     guarded = ops._f16_family() and ops.range_guard_enabled() and not torch.cuda.is_current_stream_capturing()
     if guarded:
@@ -184,16 +187,22 @@ def _range_guarded(run, x: Tensor):
     if guarded and ops.range_overflowed(x.device):
         warnings.warn("VIRNet HIP path: an activation left fp16's range in a split-fp16 convolution (|x| >= 65504, or >= ~6.5e3 in the "
                       "Winograd form); the forward was repeated with the fp32 kernels", RuntimeWarning, stacklevel=3)
-        old = os.environ.get("VIRNET_CONV_FORM")
-        os.environ["VIRNET_CONV_FORM"] = "wino"
-        try:
-            with ops.forward_scope():
-                out = run()
-        finally:
-            if old is None:
-                os.environ.pop("VIRNET_CONV_FORM", None)
-            else:
-                os.environ["VIRNET_CONV_FORM"] = old
+        _GUARD_STATS["reruns"] += 1
+        with ops.forward_scope(form=FP32_FORM):
+            out = run()
+    if guarded:
+        _GUARD_STATS["forwards"] += 1
+    return out
+
+
+_GUARD_STATS = {"forwards": 0, "reruns": 0}
+
+
+def guard_stats(reset: bool = False) -> dict:
+    """How many guarded forwards ran in this process and how many of them had to be repeated in fp32."""
+    out = dict(_GUARD_STATS)
+    if reset:
+        _GUARD_STATS["forwards"] = _GUARD_STATS["reruns"] = 0
     return out
 
 

@@ -43,9 +43,10 @@ class VIRAttResUNet(nn.Module):
             return train.denoise_forward_autograd(self, x)
         return engine.denoise_forward(self, x)
 
-    def graphed(self) -> GraphedForward:
-        """hipGraph-replayed forward for the one-image-per-call script path; outputs are reused buffers (see GraphedForward)."""
-        return GraphedForward(lambda x: engine.denoise_forward(self, x))
+    def graphed(self, check: str = "sync") -> GraphedForward:
+        """hipGraph-replayed forward for the one-image-per-call script path; outputs are reused buffers (see GraphedForward: range guard
+        around the replay, graphs dropped when a parameter changes)."""
+        return GraphedForward(lambda x: engine.denoise_forward(self, x), params=self.parameters, check=check)
 
 
 class VIRAttResUNetSR(nn.Module):
@@ -72,6 +73,6 @@ class VIRAttResUNetSR(nn.Module):
             return train_sisr.sisr_forward_train(self, x, sf)
         return engine.sisr_forward(self, x, sf)
 
-    def graphed(self) -> GraphedForward:
+    def graphed(self, check: str = "sync") -> GraphedForward:
         """hipGraph-replayed forward: `g = net.graphed(); mu, kinfo, sigma = g(x, sf)`."""
-        return GraphedForward(lambda x, sf: engine.sisr_forward(self, x, sf))
+        return GraphedForward(lambda x, sf: engine.sisr_forward(self, x, sf), params=self.parameters, check=check)

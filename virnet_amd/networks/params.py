@@ -25,8 +25,9 @@ class ConvParam(nn.Module):
         self.weight = nn.Parameter(torch.empty(shape))
         self.bias = nn.Parameter(torch.empty(cout)) if bias else None
         self.reset_parameters()
-        self._pack: Optional[ops.PackedWeight] = None
-        self._pack_key = None
+        # cached packings per conv form (the range guard's fp32 re-run must not evict the split-fp16 image): form -> (key, packing)
+        self._packs: dict = {}
+        self._dgrads: dict = {}
 
     def reset_parameters(self) -> None:
         # torch's default for _ConvNd.reset_parameters (what the reference's un-initialised convs get)
@@ -38,20 +39,26 @@ class ConvParam(nn.Module):
 
     def packed(self) -> ops.PackedWeight:
         """Packed weight for the MFMA kernel, rebuilt when the parameter storage or version changed."""
+        form = ops.conv_form()
         key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),
-               None if self.bias is None else (self.bias.data_ptr(), self.bias._version), ops.conv_form())
-        if self._pack is None or self._pack_key != key:
-            self._pack = ops.pack_weight(self.weight, self.bias, transposed=self.transposed, stride=self.stride)
-            self._pack_key = key
-        return self._pack
+               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        hit = self._packs.get(form)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weight(self.weight, self.bias, transposed=self.transposed, stride=self.stride))
+            self._packs = {f: h for f, h in self._packs.items() if h[0] == key}      # (images of an older parameter version go)
+            self._packs[form] = hit
+        return hit[1]
 
     def packed_dgrad(self) -> ops.PackedWeight:
         """Packing of this layer's input-gradient GEMM (training step), cached like ``packed``."""
-        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device), ops.conv_form())
-        if getattr(self, "_dgrad", None) is None or self._dgrad_key != key:
-            self._dgrad = ops.pack_weight(self.weight, None, transposed=self.transposed, dgrad=True)
-            self._dgrad_key = key
-        return self._dgrad
+        form = ops.conv_form()
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device))
+        hit = self._dgrads.get(form)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weight(self.weight, None, transposed=self.transposed, dgrad=True))
+            self._dgrads = {f: h for f, h in self._dgrads.items() if h[0] == key}
+            self._dgrads[form] = hit
+        return hit[1]
 
     def packed_thin(self) -> ops.PackedWeight:
         """Packing for the bandwidth-bound few-output-channel kernel (3x3, cout <= 4), cached like ``packed``."""
@@ -65,8 +72,8 @@ class ConvParam(nn.Module):
     def invalidate(self) -> None:
         """Drop the cached packings.  They follow the parameter's storage and ``_version``; a write through ``.data`` (EMA helpers,
         weight clipping) changes neither, so call this (or ``net.apply(lambda m: getattr(m, 'invalidate', lambda: None)())``) after one."""
-        self._pack = None
-        self._dgrad = None
+        self._packs = {}
+        self._dgrads = {}
         self._thin = None
 
     def forward(self, *args, **kwargs):  # pragma: no cover - guard

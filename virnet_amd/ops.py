@@ -98,21 +98,32 @@ DEFAULT_CONV_FORM = "wx4"
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
-          "VIRNET_RANGE_GUARD")
+          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
     inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The
     snapshot is per THREAD (nat.tls): forwards running in several host threads, each on its own stream, do not see each other's."""
 
+    def __init__(self, form: Optional[str] = None):
+        """``form``: override of VIRNET_CONV_FORM for this block only (the range guard's fp32 re-run) -- carried in the thread's
+        snapshot, never written to os.environ, so forwards in other threads keep their form."""
+        self._form = form
+
     def __enter__(self):
         tls = nat.tls
         self._prev = (getattr(tls, "scope_env", None), getattr(tls, "stream_cache", None))
         tls.scope_env = {k: os.environ.get(k) for k in _KNOBS}
+        self._prev_form = getattr(tls, "form_override", None)
+        if self._form is not None:
+            tls.form_override = self._form
+        if getattr(tls, "form_override", None) is not None:        # (a nested scope keeps the enclosing scope's override)
+            tls.scope_env["VIRNET_CONV_FORM"] = tls.form_override
         tls.stream_cache = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         return self
 
     def __exit__(self, *exc):
         nat.tls.scope_env, nat.tls.stream_cache = self._prev
+        nat.tls.form_override = self._prev_form
         return False
 
 
@@ -145,14 +156,18 @@ def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     images x tiles x channel blocks >= VIRNET_WX4_MIN_WGS, default 128 = half the CUs of an MI355X: measured break-even, tools/bench_conv.py --ab VIRNET_WX4_MIN_WGS=0,100000) -- single small images stay on the
     direct split-fp16 kernel, whose small-grid tile forms give the lower latency (tools/bench_latency.py).  The two forms agree to
     fp32 noise (<= 2e-5 on the network outputs), not bit for bit: with the default rule an image's result can differ in the last bits
-    between batch sizes; VIRNET_WX4_MIN_WGS=0 (or a pinned VIRNET_CONV_FORM=f16x3) restores bitwise batch independence
-    (tests/test_e2e_gpu.py holds both)."""
+    between batch sizes; VIRNET_DETERMINISTIC=1 (older spelling VIRNET_WX4_MIN_WGS=0; or a pinned VIRNET_CONV_FORM=f16x3) restores
+    bitwise batch independence (tests/test_e2e_gpu.py holds both).  Inside the Winograd form the library additionally picks the tile
+    height per launch size (csrc/conv_f16_wx4.hip: 16-row tiles / one workgroup per CU, or 8-row tiles / two per CU for launches of a
+    few hundred workgroups and the 64-channel layers); the deterministic switch pins that as well."""
     if cout < int(_env("VIRNET_WX4_MIN_COUT", "64")):          # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
         return False
     th, tw = (h + 15) // 16, (w + 31) // 32
     fill = (h * w) / float(th * 16 * tw * 32)
     if th * tw < int(_env("VIRNET_WX4_MIN_TILES", "1")) or fill < float(_env("VIRNET_WX4_MIN_FILL", "0.6")):
         return False
+    if _env("VIRNET_DETERMINISTIC", "0") == "1":           # one kernel form whatever the batch size (the library pins its tile form too)
+        return True
     return n * th * tw * ((cout + 95) // 96) >= int(_env("VIRNET_WX4_MIN_WGS", "128"))
 
 
@@ -189,16 +204,20 @@ def range_guard_enabled() -> bool:
 
 
 def range_flag(device: torch.device) -> Optional[Tensor]:
-    """The sticky int32 flag of ``device`` (created zeroed and registered with the library on first use); None when the guard is off."""
+    """The sticky int32 flag of (``device``, calling host thread) -- created zeroed and registered with the library on first use; None
+    when the guard is off.  One flag per thread: forwards driven from several host threads (each on its own stream) neither erase nor
+    trip each other's flag.  Two streams driven from ONE thread share a flag (a spurious fp32 re-run is the worst case)."""
     if not range_guard_enabled():
         return None
+    import threading
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    flag = _RANGE_FLAGS.get(idx)
+    key = (idx, threading.get_ident())
+    flag = _RANGE_FLAGS.get(key)
     if flag is None:
         flag = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
         with torch.cuda.device(idx):
             nat.check(nat.load().virnet_set_range_flag(nat.ptr(flag)), "set_range_flag")
-        _RANGE_FLAGS[idx] = flag
+        _RANGE_FLAGS[key] = flag
     return flag
 
 
@@ -211,6 +230,11 @@ def range_overflowed(device: torch.device, *, reset: bool = True) -> bool:
     if reset:
         flag.zero_()
     return True
+
+
+def poison_on_flag(flag: Tensor, y: Tensor) -> None:
+    """NaN-fill ``y`` on the device when ``flag`` is up (virnet_poison_on_flag): the tail of a replayed graph, see graph.py."""
+    nat.check(nat.load().virnet_poison_on_flag(nat.ptr(flag), nat.ptr(y), y.numel(), nat.stream_handle()), "poison_on_flag")
 
 
 def pack_f16_weight(weight: Tensor, *, dgrad: bool = False, bf16: bool = False) -> Tensor:
@@ -660,7 +684,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
         cout, cin, ks = weight_shape[0], weight_shape[1], weight_shape[2]
     form = conv_form()
     if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16", "wx4")
-            and os.environ.get("VIRNET_WGRAD_FORM", "f16") != "f32"):
+            and _env("VIRNET_WGRAD_FORM", "f16") != "f32"):
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
         return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
                                bias_channels=bias_channels)

@@ -69,10 +69,10 @@ def forward_tiled_sisr(net, x: torch.Tensor, sf: int, tile: int = 256, overlap: 
     if not net.noise_avg:
         raise ValueError("forward_tiled_sisr is for noise_avg=True models (per-pixel conditioning tiles with forward_tiled)")
     sf = int(sf)
-    with torch.no_grad(), torch.cuda.device(x.device):
-        x = engine._prep(x, net.SNet.in_channels)
-        sigma = engine.snet_forward(net.SNet, x, mode="sigma")                # [1,s,1,1]
-        kinfo = engine.knet_forward(net.KNet, x)                              # [1,k,1,1]
+    def run():
+        xx = engine._prep(x, net.SNet.in_channels)
+        sigma = engine.snet_forward(net.SNet, xx, mode="sigma")               # [1,s,1,1]
+        kinfo = engine.knet_forward(net.KNet, xx)                             # [1,k,1,1]
         parts = []
         if net.kernel_cond:
             parts.append(kinfo.view(1, -1))
@@ -84,5 +84,9 @@ def forward_tiled_sisr(net, x: torch.Tensor, sf: int, tile: int = 256, overlap: 
             v = None if vec is None else vec.expand(t.shape[0], -1).contiguous()
             return engine.rnet_forward(net.RNet, t.contiguous(), extra_vec=v, sf=sf, map_sf=sf, map_sqrt=True)
 
-        mu = forward_tiled(rnet, x, tile=tile, overlap=overlap, scale=sf, batch=batch, multiple=1 << (net.RNet.depth - 1))
-    return mu, kinfo.view(1, -1), sigma
+        mu = forward_tiled(rnet, xx, tile=tile, overlap=overlap, scale=sf, batch=batch, multiple=1 << (net.RNet.depth - 1))
+        return mu, kinfo.view(1, -1), sigma
+
+    # (the sub-network forwards are called directly: the range guard and the per-forward knob / stream snapshot wrap the whole image)
+    with torch.no_grad(), torch.cuda.device(x.device):
+        return engine._range_guarded(run, x)
