@@ -146,3 +146,50 @@ def test_bench_train_two_ranks_averages_gradients():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "gradient all-reduce per step" in d["config"]["parallelism"]
     assert d["config"]["global_batch"] == 8 and d["value"] > 0
+
+
+def _worker_scales(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      VIRNET_DIST_BACKEND="gloo")
+    from virnet_amd import dist as vdist
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    vdist.init()
+    dev = torch.device("cuda", 0)
+    cfg = dict(sigma_chn=1, n_feat=[64, 96], dep_S=3, n_resblocks=1)
+    net = VIRAttResUNet(3, **cfg).to(dev)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=4))
+    plain = VIRAttResUNet(3, **cfg).to(dev)
+    plain.load_state_dict(net.state_dict())
+    ddp = vdist.DistributedTrainer(net, bucket_bytes=1 << 18)
+    factors = (1.0, 3.0e-6)                                  # the ranks' incoming gradients sit 18 binades apart
+    xs = [synth_images(2, 3, 16, 32, seed=20 + r).to(dev) for r in range(world)]
+    gts = [synth_images(2, 3, 16, 32, seed=30 + r).to(dev) for r in range(world)]
+
+    def loss_of(m, r):
+        mu, sigma = m(xs[r])
+        return (((mu - gts[r]) ** 2).mean() + 0.1 * sigma.mean()) * factors[r]
+    loss_of(ddp, rank).backward()
+    got = {k: p.grad.double().clone() for k, p in net.named_parameters()}
+    want = None
+    for r in range(world):                                   # what the average must be: every rank's term from a plain single-rank backward
+        for p in plain.parameters():
+            p.grad = None
+        loss_of(plain, r).backward()
+        term = {k: p.grad.double() / world for k, p in plain.named_parameters()}
+        want = term if want is None else {k: want[k] + term[k] for k in want}
+    worst = 0.0
+    for k in want:
+        worst = max(worst, float((got[k] - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-30))
+    ret[rank] = dict(worst=worst, gsum=float(torch.cat([g.reshape(-1) for g in got.values()]).sum()))
+    dist.destroy_process_group()
+
+
+def test_distributed_trainer_ranks_with_different_loss_scales():
+    """ADVICE r03 (train.py:243): the backward's power-of-two rescaling must use ONE factor on every rank, or the all-reduced sum mixes
+    differently scaled terms.  Two ranks whose losses differ by 3e5: every rank ends with mean_k(f_k g_k), identical on both."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_scales, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0]["gsum"] == ret[1]["gsum"]
+    assert ret[0]["worst"] <= 1e-4 and ret[1]["worst"] <= 1e-4, (ret[0]["worst"], ret[1]["worst"])

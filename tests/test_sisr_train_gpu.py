@@ -85,11 +85,56 @@ def test_sisr_backward_does_not_depend_on_the_loss_scale(factor):
         return {k: p.grad.double().clone() for k, p in net.named_parameters()}
 
     base, scaled = grads(1.0), grads(factor)
-    assert net._sisr_grad_scale.scale != 1.0
     for k in base:
         ref, got = base[k], scaled[k] / factor
         assert bool(torch.isfinite(got).all()), k
         assert float((got - ref).abs().max()) <= 1e-4 * max(float(ref.abs().max()), 1e-30), (k, factor)
+
+
+def test_sisr_unscale_lives_in_the_graph():
+    """The unscale is an autograd node of the forward it belongs to (train_sisr._Gate), not a hook on the leaves: a
+    deep-copied module, a module with frozen sub-networks and two forwards folded into ONE backward (each with its own power of two)
+    all give the gradients of the scaled loss."""
+    import copy
+    net, _ = build(SMALL)
+    x1, x2 = synth_images(2, 3, 12, 20).cuda(), synth_images(2, 3, 12, 20, seed=5).cuda()
+    gt1, gt2 = synth_images(2, 3, 24, 40, seed=2).cuda(), synth_images(2, 3, 24, 40, seed=6).cuda()
+
+    def grads(m, terms):
+        for p in m.parameters():
+            p.grad = None
+        loss = 0.0
+        for xx, gg, f in terms:
+            mu, kinfo, sigma = m(xx, 2)
+            loss = loss + surrogate_loss(mu, kinfo, sigma, gg) * f
+        loss.backward()
+        return {k: (None if p.grad is None else p.grad.double().clone()) for k, p in m.named_parameters()}
+
+    def close(got, ref, what):
+        for k in ref:
+            if ref[k] is None:
+                assert got[k] is None, (what, k)
+                continue
+            assert bool(torch.isfinite(got[k]).all()), (what, k)
+            assert float((got[k] - ref[k]).abs().max()) <= 1e-4 * max(float(ref[k].abs().max()), 1e-30), (what, k)
+
+    g1, g2 = grads(net, [(x1, gt1, 1.0)]), grads(net, [(x2, gt2, 1.0)])
+    assert not any(h for p in net.parameters() for h in (getattr(p, "_backward_hooks", None) or {}).values())   # no leaf hooks
+    # (1) a deep copy made AFTER the original has run
+    twin = copy.deepcopy(net)
+    close({k: v / 1e6 for k, v in grads(twin, [(x1, gt1, 1e6)]).items()}, g1, "deepcopy")
+    # (2) two forwards, one backward, factors 2^43 apart: each sub-graph is unscaled by its own factor
+    both = grads(net, [(x1, gt1, 1e6), (x2, gt2, 1e-7)])
+    close(both, {k: 1e6 * g1[k] + 1e-7 * g2[k] for k in g1}, "two forwards")
+    both = grads(net, [(x1, gt1, 1e-7), (x2, gt2, 1e6)])
+    close(both, {k: 1e-7 * g1[k] + 1e6 * g2[k] for k in g1}, "two forwards, swapped")
+    # (3) frozen sub-networks (fine-tuning): no gradient for them, the rest unchanged
+    for p in net.SNet.parameters():
+        p.requires_grad_(False)
+    frozen = grads(net, [(x1, gt1, 1e6)])
+    assert all(v is None for k, v in frozen.items() if k.startswith("SNet."))
+    close({k: (None if v is None else v / 1e6) for k, v in frozen.items() if not k.startswith("SNet.")},
+          {k: v for k, v in g1.items() if not k.startswith("SNet.")}, "frozen SNet")
 
 
 def test_sisr_training_loop_shape():

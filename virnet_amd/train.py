@@ -240,6 +240,12 @@ class DenoiseFunction(torch.autograd.Function):
             for g in (dmu, dsigma):
                 if g is not None:
                     amax = torch.maximum(amax, g.detach().abs().amax())
+            if reducer is not None and reducer.world > 1:
+                # every rank must use the SAME factor: the scaled gradients are summed across ranks inside the backward (reducer.push)
+                # and unscaled afterwards -- with per-rank factors rank r would get (1/s_r) * mean_k(s_k g_k).  One 4-byte MAX
+                # all-reduce on the device, ordered on the stream like every other collective: still no host sync.
+                import torch.distributed as dist
+                dist.all_reduce(amax, op=dist.ReduceOp.MAX, group=reducer.group)
             scale = torch.exp2(torch.clamp(-torch.floor(torch.log2(amax.clamp_min(1e-37))) - 1.0, -100.0, 100.0))
             scale = torch.where(amax > 0, scale, torch.ones_like(scale))
             dmu = None if dmu is None else dmu * scale

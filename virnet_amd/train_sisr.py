@@ -313,11 +313,11 @@ def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int) -> Tensor:
 # nothing -- while the largest incoming entry lies in [2^-10, 2^10]; deciding that costs one device -> host read per backward.
 # ----------------------------------------------------------------------------------------------------------------------
 class _GradScaleState:
+    """The factor of ONE forward: written by that forward's _Boundary node, read by its _Gate node.  Never shared between forwards,
+    modules or copies of a module."""
+
     def __init__(self):
         self.scale = 1.0
-
-    def __deepcopy__(self, memo):      # the parameter hooks of a copied module still point at THIS object: the copy must share it
-        return self
 
 
 class _Boundary(torch.autograd.Function):
@@ -339,14 +339,25 @@ class _Boundary(torch.autograd.Function):
         return tuple(None if g is None else g * scale for g in (dmu, dkinfo, dsigma)) + (None,)
 
 
-def _install_unscale_hooks(net) -> _GradScaleState:
-    state = getattr(net, "_sisr_grad_scale", None)
-    if state is None:
-        state = _GradScaleState()
-        for p in net.parameters():
-            p.register_hook(lambda g, st=state: g if st.scale == 1.0 else g * (1.0 / st.scale))   # (a power of two: exact)
-        net._sisr_grad_scale = state
-    return state
+class _Gate(torch.autograd.Function):
+    """Identity on the trainable parameters at the ENTRY of a forward; its backward divides their gradients by the factor the same
+    forward's _Boundary node chose (it runs first: it sits behind every use).  The unscale therefore lives inside the autograd graph of
+    the forward it belongs to -- no hooks on the leaves: nothing to lose in copy.deepcopy, nothing to trip over frozen parameters,
+    parameters added later are simply gated by the next forward, and two forwards folded into one backward each use their own factor
+    (train_sisr.py:319)."""
+
+    @staticmethod
+    def forward(ctx, state, *params):
+        ctx.state = state
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        s = ctx.state.scale
+        if s == 1.0:
+            return (None,) + grads
+        inv = 1.0 / s                                                   # (a power of two: exact)
+        return (None,) + tuple(None if g is None else g * inv for g in grads)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -364,7 +375,11 @@ def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     if net.noise_cond and not net.noise_avg:
         raise NotImplementedError("VIRAttResUNetSR training with a per-pixel variance map (noise_avg=False) is not built: the SFT layers "
                                   "would need per-pixel modulation gradients; train with noise_avg=True (the reference's default)")
-    with torch.cuda.device(x.device):
+    state = _GradScaleState()
+    named = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
+    gated = _Gate.apply(state, *[p for _, p in named]) if named else ()
+    # the forward below reads the modules' attributes: swap the gated views in for its duration (what torch.func.functional_call does)
+    with torch.nn.utils.stateless._reparametrize_module(net, {k: g for (k, _), g in zip(named, gated)}), torch.cuda.device(x.device):
         sigma = torch.exp(torch.clamp(_snet(net.SNet, x), min=LOG_MIN, max=LOG_MAX))          # VIRNet.py:81
         kinfo = _knet(net.KNet, x)                                                            # VIRNet.py:82
         parts = []
@@ -374,4 +389,4 @@ def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
             parts.append(sigma.view(n, -1).sqrt())                                            # VIRNet.py:92
         vec = torch.cat(parts, 1) if parts else None
         mu = _rnet(net.RNet, x, vec, sf)
-    return _Boundary.apply(mu, kinfo, sigma, _install_unscale_hooks(net))
+    return _Boundary.apply(mu, kinfo, sigma, state)
