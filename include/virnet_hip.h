@@ -303,6 +303,18 @@ int virnet_scale_add(const float* hcv, const float* gate, const float* skip, flo
 int virnet_ca_scale_add(const float* hcv, const float* w1, const float* b1, const float* w2, const float* b2, const float* skip,
                         float* out, int n, int h, int w, int c, int cr, void* stream);
 
+/* KernelNet body as ONE persistent kernel (KNet.py:28-39,46-48,54: `nlayers` RB_Layers = conv3x3 + LeakyReLU(0.2) + conv3x3 + CALayer +
+ * skip, each), one workgroup per image holding the h x w x 64 map on the CU (csrc/knet_body.hip): for maps of at most 16 x 16 pixels
+ * (LR images up to 64 x 64 behind the stride-4 head).  x, y: NHWC [n][h][w][64] fp32 (y may alias x).  Per layer: w1pack / w2pack =
+ * virnet_pack_f16_weight images of the two 64->64 convs (cin_pad = n_pad = 64), b1 / b2 their biases (NULL = none), caw1 [cr][64], cab1
+ * [cr], caw2 [64][cr], cab2 [64] the CALayer's 1x1 convs.  Same split-fp16 arithmetic per product as virnet_conv_f16; the channel means
+ * are summed in a fixed order (bitwise reproducible).  Larger maps: virnet_conv_f16 + virnet_ca_scale_add per layer. */
+typedef struct virnet_knet_layer {
+  const float *w1pack, *b1, *w2pack, *b2;
+  const float *caw1, *cab1, *caw2, *cab2;
+} virnet_knet_layer;
+int virnet_knet_body(const float* x, float* y, const virnet_knet_layer* layers, int nlayers, int n, int h, int w, int c, int cr, void* stream);
+
 /* AttLayer weights (AttResUNet.py:18-25), all 1x1 convs stored [cout][cin]. */
 typedef struct virnet_sft_weights {
   const float *w1, *b1;   /* [nf1][e]   */

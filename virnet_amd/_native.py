@@ -65,6 +65,11 @@ class WgradDesc(C.Structure):
     ]
 
 
+class KnetLayer(C.Structure):
+    """virnet_knet_layer (include/virnet_hip.h)"""
+    _fields_ = [(k, C.c_void_p) for k in ("w1pack", "b1", "w2pack", "b2", "caw1", "cab1", "caw2", "cab2")]
+
+
 class SftWeights(C.Structure):
     _fields_ = [
         ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
@@ -130,6 +135,7 @@ SYMBOLS = [
                                   C.c_float, C.c_void_p]),
     ("virnet_ca_gate", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_knet_body", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_scale_add", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_ca_scale_add", C.c_int, [C.c_void_p] * 7 + [C.c_int] * 5 + [C.c_void_p]),
     ("virnet_sft_vec", C.c_int, [C.c_void_p, C.POINTER(SftWeights), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

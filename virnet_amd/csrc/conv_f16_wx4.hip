@@ -296,6 +296,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   float sbv = 0.f;                                 // this thread's entry of the [inverse scale | bias] table
   if (tid < NB) sbv = a.inv_scale[nbase + tid];
   else if (tid < 2 * NB && a.bias) sbv = a.bias[nbase + tid - NB];
+#ifdef WX4_PROBE_2X
+  // probe build (profiles/r04_probes.md 4): prologue and plain epilogue executed a.nchw_op times -- what ONE prologue + epilogue pair
+  // costs in launch time under the real power / memory conditions (the upper bound of what res-block fusion could delete)
+  for (int prep = 0; prep < a.nchw_op; ++prep) {
+  if (prep) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 #pragma unroll
   for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds);
   ldp(WX_I(0)); ldp(WX_I(1)); ldp(WX_I(2)); ldp(WX_I(3)); ldp(WX_I(4)); ldp(WX_I(5));
@@ -311,6 +317,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   pA(WX_I(1), WX_I(4)); pB(WX_I(1), WX_I(4)); pV(WX_I(1), WX_I(4)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(4));
   hSa(WX_I(0)); hSb(WX_I(0)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(0));
   hSa(WX_I(1)); hSb(WX_I(1)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(1));
+#ifdef WX4_PROBE_2X
+  }
+#endif
   if (tid < 2 * NB) sb_lds[tid] = sbv;
   __syncthreads();
   TSTAMP(1);
@@ -489,9 +498,13 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       for (int it = 0; it < NIT; ++it)
         op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, 0));
     };
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
+#ifdef WX4_PROBE_2X
+    for (int erep = 0; erep < (EPI == 0 ? a.nchw_op : 1); ++erep) {
+    if (erep) wx_lds_barrier();
+#endif
     xwrite(0);
     if (EPF && NREP > 1) load_op1(1);
-    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
 #pragma unroll
     for (int nr = 0; nr < NREP; ++nr) {
       if (nr > 0) xwrite(nr);
@@ -529,6 +542,9 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       if (nr == 0) TSTAMP(7);
       if (nr + 1 < NREP) wx_lds_barrier();
     }
+#ifdef WX4_PROBE_2X
+    }
+#endif
   } else {
     // generic form (two stored tensors and / or SFT on the output): optional operands by runtime pointer
     const char* const rimg = a.res ? reinterpret_cast<const char*>(a.res + img_off) : nullptr;
@@ -686,6 +702,9 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
 #endif
   hipStream_t st = static_cast<hipStream_t>(stream);
   k.range_flag = virnet::range_flag_ptr();
+#ifdef WX4_PROBE_2X
+  k.nchw_op = getenv("WX4_PROBE_REPS") ? atoi(getenv("WX4_PROBE_REPS")) : 1;
+#endif
   const int nb = d->n_pad / 32;
   const int epi = (d->mul || (d->y_raw && d->y_act)) ? 4 : (d->res ? 1 : 0) | (d->mask ? 2 : 0);
   const int pre = d->in_mul ? 2 : (d->in_act != 0);

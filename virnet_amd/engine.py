@@ -80,7 +80,13 @@ def knet_forward(knet, x: Tensor) -> Tensor:
     x = _prep(x, knet.in_nc)
     n, _, h, w = x.shape
     cur = ops.conv_head_s4(x, knet.head.weight)                                  # KNet.py:45,53 -> NHWC raw
-    for rb in knet.body:
+    persistent = (ops._f16_family() and cur.shape[3] == 64 and max(cur.shape[1:3]) <= ops.KNET_BODY_MAX and len(knet.body) > 0
+                  and ops._env("VIRNET_KNET_PERSISTENT", "1") != "0")
+    if persistent:
+        # the whole body in ONE launch, the map resident on one CU per image (csrc/knet_body.hip; KNet.py:28-39,46-48,54)
+        cur = ops.knet_body(cur, [(rb.body["0"].packed(), rb.body["2"].packed(), rb.body["3"].body["0"].weight, rb.body["3"].body["0"].bias,
+                                   rb.body["3"].body["2"].weight, rb.body["3"].body["2"].bias) for rb in knet.body])
+    for rb in (() if persistent else knet.body):
         _, a = ops.conv_mfma(cur, rb.body["0"].packed(), want_raw=False, want_act=True, slope=0.2)   # KNet.py:32-33
         hcv, _ = ops.conv_mfma(a, rb.body["2"].packed(), want_raw=True)                               # KNet.py:34
         ca = rb.body["3"].body

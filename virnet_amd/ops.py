@@ -98,7 +98,7 @@ DEFAULT_CONV_FORM = "wx4"
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
-          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC")
+          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
     inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The
@@ -612,6 +612,32 @@ def ca_scale_add(hcv: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, sk
     out = torch.empty_like(hcv)
     nat.check(nat.load().virnet_ca_scale_add(nat.ptr(hcv), *(nat.ptr(t) for t in ts), nat.ptr(skip), nat.ptr(out), n, h, w, c, w1.shape[0],
                                              nat.stream_handle()), "ca_scale_add")
+    return out
+
+
+KNET_BODY_MAX = 16      # largest map side virnet_knet_body keeps on one CU
+
+
+def knet_body(x: Tensor, layers) -> Tensor:
+    """KernelNet's RB_Layers in ONE launch (csrc/knet_body.hip): ``x`` NHWC [n,h,w,64] with h, w <= 16; ``layers`` = one tuple
+    (conv1 packing, conv2 packing, CALayer w1, b1, w2, b2) per RB_Layer, the packings carrying their split-fp16 image."""
+    _dev_check(x, "x")
+    n, h, w, c = x.shape
+    arr = (nat.KnetLayer * len(layers))()
+    keep = []
+    for i, (p1, p2, w1, b1, w2, b2) in enumerate(layers):
+        if p1.f16 is None or p2.f16 is None:
+            raise RuntimeError("knet_body needs the split-fp16 weight images (VIRNET_CONV_FORM of the f16 family)")
+        ts = [t.detach() for t in (w1, b1, w2, b2)]
+        for t in ts:
+            _dev_check(t, "CALayer parameter")
+        keep.append(ts)
+        arr[i] = nat.KnetLayer(nat.ptr(p1.f16), 0 if p1.bias is None else nat.ptr(p1.bias), nat.ptr(p2.f16), 0 if p2.bias is None else nat.ptr(p2.bias),
+                               *(nat.ptr(t) for t in ts))
+    out = torch.empty_like(x)
+    cr = layers[0][2].shape[0]
+    nat.check(nat.load().virnet_knet_body(nat.ptr(x), nat.ptr(out), C.cast(arr, C.c_void_p), len(layers), n, h, w, c, cr, nat.stream_handle()),
+              "knet_body")
     return out
 
 
