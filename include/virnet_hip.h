@@ -166,6 +166,16 @@ size_t virnet_wx4_weight_floats(int cin_pad, int n_pad);
 int virnet_pack_wx4_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
 int virnet_conv_wx4(const virnet_conv_desc* d, void* stream);
 
+/* Few-output-channel exits with planar store (csrc/conv_exit.hip): AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173),
+ * DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43), KernelNet.tail (KNet.py:49) -- for cout * 9 <= 32 the (channel, tap) pairs
+ * are the ROWS of one pointwise split-fp16 GEMM and the taps are summed afterwards: the input is read once, straight into MFMA
+ * fragments (HBM-bound; algorithmic bytes n*h*w*cin_pad*4 in + 4 per output value).  `d` as for virnet_conv_f16 with epi =
+ * VIRNET_EPI_NCHW (nchw_op, crop, res / res_sf, clamp honoured; in_act / in_slope optional); wpack from virnet_pack_exit_weight:
+ * 32 inverse row scales, then [cin_pad/16][hi|lo][64 lanes][8 x fp16]. */
+size_t virnet_exit_weight_floats(int cin_pad);
+int virnet_pack_exit_weight(const float* w_oihw, int cout, int cin, int cin_pad, float* packed, void* stream);
+int virnet_conv_exit(const virnet_conv_desc* d, void* stream);
+
 /* Range guard of the split-fp16 kernels (virnet_conv_f16 incl. its stride-2 / transposed forms, virnet_conv_wx4).  An operand of magnitude
  * >= 65520 (transformed magnitude for virnet_conv_wx4: up to 10x the activation) does not fit fp16: the product turns Inf / NaN, which is
  * loud in a tensor but clamped away by the exp(clamp(.)) / tanh epilogues (VIRNet.py:43, KNet.py:56-58).  Register a zeroed device int per

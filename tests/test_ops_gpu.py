@@ -180,6 +180,53 @@ def test_thin_conv_kernel(c, cout, h, w, n):
         ops.pack_thin_weight(torch.zeros(5, 16, 3, 3, device="cuda"), None)
 
 
+@pytest.mark.parametrize("form", ["rows", "f16"])
+@pytest.mark.parametrize("c,cout,h,w,n", [(96, 3, 12, 36, 2), (64, 1, 9, 40, 1), (64, 3, 17, 33, 2), (64, 2, 8, 32, 3), (160, 3, 8, 70, 1), (96, 3, 1, 1, 1),
+                                           (96, 3, 67, 130, 2)])
+def test_exit_conv_planar(monkeypatch, form, c, cout, h, w, n):
+    """The few-output-channel exits on the split-fp16 path: the taps-as-rows kernel (csrc/conv_exit.hip, default for cout <= 3) and
+    conv_f16's planar form -- plain, crop + residual (also through nearest x2), exp(clamp), against fp64 and the oracle's conv."""
+    monkeypatch.setenv("VIRNET_CONV_FORM", "wx4")
+    monkeypatch.setenv("VIRNET_EXIT_FORM", form)
+    cp = make_conv(c, cout)
+    x = rnd(n, c, h, w, seed=50)
+    v = F.conv2d(x.double(), cp.weight.detach().double(), cp.bias.detach().double(), padding=1).float()
+    assert maxerr(cpu_ref.conv_fused(x, cp.weight.detach(), cp.bias.detach())[0], v) <= TOL
+    cp.cuda()
+    pw = cp.packed()
+    assert (pw.exit is not None) == (cout <= 3)
+    calls = []
+    lib = nat.load()
+    real = lib.virnet_conv_exit
+    monkeypatch.setattr(lib, "virnet_conv_exit", lambda *a: (calls.append(1), real(*a))[1])
+    assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w)).cpu(), v) <= TOL
+    assert bool(calls) == (form == "rows")
+    if h > 2 and w > 3:
+        ch, cw = h - 2, w - 3
+        xin = rnd(n, cout, ch, cw, seed=51)
+        assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (ch, cw), op=nat.NCHW_ADD, res=xin.cuda()).cpu(), v[..., :ch, :cw] + xin) <= TOL
+    if h % 2 == 0 and w % 2 == 0:
+        xlr = rnd(n, cout, h // 2, w // 2, seed=52)
+        ref = v + F.interpolate(xlr, scale_factor=2, mode="nearest")
+        assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w), op=nat.NCHW_ADD, res=xlr.cuda(), res_sf=2).cpu(), ref) <= TOL
+    ref = torch.exp(torch.clamp(v, min=-0.5, max=0.7))
+    assert maxerr(ops.conv_f16_nchw(nhwc(x), pw, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(-0.5, 0.7)).cpu(), ref) <= TOL
+
+
+def test_exit_conv_range_flag_and_bad_descriptors():
+    cp = make_conv(96, 3).cuda()
+    pw = cp.packed()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.range_flag(dev).zero_()
+    x = rnd(1, 96, 8, 40, seed=3)
+    x[0, 5, 3, 3] = 7.0e4
+    out = ops.conv_f16_nchw(nhwc(x), pw, (8, 40))
+    assert ops.range_overflowed(dev) and not bool(torch.isfinite(out).all())
+    with pytest.raises(RuntimeError, match="cout <= 3"):
+        lib = nat.load()
+        nat.check(lib.virnet_pack_exit_weight(nat.ptr(cp.weight.detach()), 4, 96, 96, nat.ptr(pw.exit), nat.stream_handle()), "pack_exit")
+
+
 def test_pack_input_reflect_upsample_concat():
     """Entry kernel vs pad_input / interpolate / cat (util_net.py:20-25, VIRNet.py:83-95, AttResUNet.py:153)."""
     x, sig = rnd(2, 3, 37, 45, seed=16, lo=0, hi=1), rnd(2, 1, 37, 45, seed=17, lo=0.1, hi=2)

@@ -33,6 +33,7 @@ class PackedWeight:
     f16: Optional[Tensor] = None    # split-fp16 image (virnet_pack_f16_weight) of a stride-1 3x3 layer, when eligible
     bf16: Optional[Tensor] = None   # bf16-operand image (virnet_pack_bf16_weight) of a C->C stride-1 3x3 layer (form "bf16" only)
     wx4: Optional[Tensor] = None    # Winograd F(4,3)-along-x split-fp16 image (virnet_pack_wx4_weight) of a C->C stride-1 3x3 layer (form "wx4")
+    exit: Optional[Tensor] = None   # taps-as-rows split-fp16 image (virnet_pack_exit_weight) of a 3x3 layer with <= 3 output channels
 
 
 class LaunchTimer:
@@ -98,7 +99,7 @@ DEFAULT_CONV_FORM = "wx4"
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
-          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT")
+          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
     inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The
@@ -357,6 +358,9 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
             # every stride-1 3x3 layer: the C->C convs, the few-input-channel entry convs (HBM-bound: one 16-channel chunk) and, through
             # the planar store, the few-output-channel exits
             pw.f16 = pack_f16_weight(weight)
+            if cout * 9 <= 32:                                    # tail / conv_last / KNet tail: csrc/conv_exit.hip
+                pw.exit = torch.empty(lib.virnet_exit_weight_floats(plan.cin_pad), dtype=torch.float32, device=weight.device)
+                nat.check(lib.virnet_pack_exit_weight(nat.ptr(weight), cout, cin, plan.cin_pad, nat.ptr(pw.exit), nat.stream_handle()), "pack_exit_weight")
             if conv_form() == "bf16" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
                 pw.bf16 = pack_f16_weight(weight, bf16=True)
             if conv_form() == "wx4" and cout % 32 == 0 and cin >= WINO_MIN_CHANNELS:
@@ -460,20 +464,23 @@ def conv_f16_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: 
         _dev_check(res, "res")
         if tuple(res.shape) != (n, pw.cout, ch // res_sf, cw // res_sf):
             raise ValueError(f"res shape {tuple(res.shape)} != {(n, pw.cout, ch // res_sf, cw // res_sf)}")
-    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0, mask=0,
+    lib = nat.load()
+    # taps-as-rows exit kernel (csrc/conv_exit.hip) when the (channel, tap) pairs fit one MFMA block; VIRNET_EXIT_FORM=f16 keeps conv_f16's planar form
+    use_exit = pw.exit is not None and _env("VIRNET_EXIT_FORM", "rows") != "f16"
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.exit if use_exit else pw.f16), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=0, add=0, mask=0,
                      mask_slope=0.0, in_mul=0, in_add=0, in_act=0, in_slope=0.0, y_raw=nat.ptr(out), y_act=0, n=n, h=h, w=w, cin_pad=c, cout=pw.cout,
                      n_pad=32, nrep=1, ks=3, stride=1, epi=nat.EPI_NCHW, nchw_op=op, crop_h=ch, crop_w=cw,
                      res_sf=res_sf, slope=0.0, clamp_lo=clamp[0], clamp_hi=clamp[1])
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 9
-    lib = nat.load()
+    fn, what = (lib.virnet_conv_exit, "conv_exit") if use_exit else (lib.virnet_conv_f16, "conv_f16(nchw)")
     if _TIMER is None:
-        nat.check(lib.virnet_conv_f16(C.byref(d), nat.stream_handle()), "conv_f16(nchw)")
+        nat.check(fn(C.byref(d), nat.stream_handle()), what)
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.check(lib.virnet_conv_f16(C.byref(d), nat.stream_handle()), "conv_f16(nchw)")
+        nat.check(fn(C.byref(d), nat.stream_handle()), what)
         e1.record()
-        _TIMER.records.append((("f16x3", pw.cout), flops, e0, e1))
+        _TIMER.records.append((("exit" if use_exit else "f16x3", pw.cout), flops, e0, e1))
     return out
 
 
