@@ -260,6 +260,11 @@ def main():
         raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # (modulo: lets a 1-GPU box rehearse N ranks over gloo)
     torch.cuda.set_device(dev)
+    if world > 1:
+        # N Python processes share the host: cap every rank's CPU thread pool (torch's default is one thread per core, i.e. N x 256
+        # runnable threads on the 8-GPU node) -- the hot path enqueues kernels from ONE thread, the pools only serve host-side glue
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, min(8, cores // world)))
 
     net, sd = build_net(dev, "sisr" if sisr else "denoise")
     fwd = (lambda t: net(t, 4)) if sisr else net
@@ -349,13 +354,36 @@ def main():
         ops.set_launch_timer(timer)     # two event records per conv launch, on the launch stream (~us of host time each)
         with (PowerSampler(dev.index) if rank == 0 else _Null()) as psamp:
             t0 = time.perf_counter()
+            c0 = time.thread_time()
             for _ in range(args.steps):
                 mu = fwd(x)[0]
+            host_enqueue = time.perf_counter() - t0          # wall time until the K steps are enqueued (the device runs behind; a full
+            host_cpu = time.thread_time() - c0               # launch queue blocks here) and the CPU time this thread spent doing it
             torch.cuda.synchronize()
             barrier()
             elapsed = time.perf_counter() - t0
         ops.set_launch_timer(None)
         power = psamp.summary() if rank == 0 else None
+        # what ONE step costs the host with an empty launch queue (all ranks at once: N processes share the host's cores) -- the
+        # number a rank's device time per step must exceed for the rank not to be host-bound
+        # (measured with the range guard's end-of-forward flag read switched off for these three steps: the read waits for the device)
+        one = []
+        guard_env = os.environ.get("VIRNET_RANGE_GUARD")
+        os.environ["VIRNET_RANGE_GUARD"] = "0"
+        try:
+            for _ in range(3):
+                torch.cuda.synchronize()
+                barrier()
+                t1 = time.perf_counter()
+                fwd(x)
+                one.append(time.perf_counter() - t1)
+        finally:
+            if guard_env is None:
+                os.environ.pop("VIRNET_RANGE_GUARD", None)
+            else:
+                os.environ["VIRNET_RANGE_GUARD"] = guard_env
+        torch.cuda.synchronize()
+        host_one_step = sorted(one)[1]
         # A second, longer region (the contract's K steps are ~0.4 s: short against the firmware's power averaging and the box-to-box
         # spread): >= 50 steps when that stays under ~5 s.  Reported beside `value`, never instead of it.
         steady = None
@@ -380,7 +408,10 @@ def main():
     if world > 1:
         props = torch.cuda.get_device_properties(dev)
         mine = {"rank": rank, "device_index": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name,
-                "images_per_s": round((b - a) * args.steps / elapsed_local, 2), "seconds": round(elapsed_local, 4)}
+                "images_per_s": round((b - a) * args.steps / elapsed_local, 2), "seconds": round(elapsed_local, 4),
+                "host_ms_one_step_empty_queue": round(host_one_step * 1e3, 3),
+                "enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3), "host_cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 3),
+                "cpu_threads": torch.get_num_threads()}
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
         try:

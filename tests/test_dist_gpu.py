@@ -193,3 +193,32 @@ def test_distributed_trainer_ranks_with_different_loss_scales():
     mp.spawn(_worker_scales, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0]["gsum"] == ret[1]["gsum"]
     assert ret[0]["worst"] <= 1e-4 and ret[1]["worst"] <= 1e-4, (ret[0]["worst"], ret[1]["worst"])
+
+
+def test_bench_eight_rank_rehearsal_is_not_host_bound():
+    """Pre-flight of the driver's 8-GPU run on the one GPU of this box (gloo, 4 images per rank): `bench.py --gpus 8` self-spawns 8
+    ranks, every rank reports, the one flat weight broadcast is 42 157 328 bytes, and with 8 Python processes sharing the host no rank
+    needs more host time to ENQUEUE a step than a fraction of what the metric's 32-image step takes on the device (~22 ms): the ranks'
+    CPU thread pools are capped (bench.py), the hot path enqueues from one thread."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIRNET_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--batch", "4", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 32 and d["config"]["images_per_gpu"] == 4
+    mg = d["multi_gpu"]
+    assert mg["backend"] == "gloo" and sorted(r["rank"] for r in mg["per_rank"]) == list(range(8))
+    assert mg["ranks_seen"] == 1 and mg["broadcast_bytes"] == 42157328
+    assert d["value"] == pytest.approx(32 * 4 / (d["ms_per_step"] * 4e-3), rel=1e-3)
+    for r in mg["per_rank"]:
+        assert r["images_per_s"] > 0 and 1 <= r["cpu_threads"] <= 8, r
+        # enqueueing one step on an empty queue, 8 processes at it together: << the 22 ms the 32-image step keeps a GPU busy
+        # (enqueue_ms_per_step is NOT that: with the 8 ranks time-sharing this box's one GPU the launch queue fills and the call blocks)
+        assert r["host_ms_one_step_empty_queue"] <= 8.0, r
