@@ -19,6 +19,7 @@ from virnet_amd.utils.synth import synth_images, synth_state_dict  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
+    ap.add_argument("--check", default="sync", choices=["sync", "deferred", "off"], help="range-guard mode of the replayed graph (graph.py)")
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
     net = VIRAttResUNet(im_chn=3, sigma_chn=1, **SYN_CFG)
@@ -26,7 +27,7 @@ def main():
     net = net.cuda().eval()
     for shape in [(1, 3, 481, 321), (1, 3, 256, 256), (1, 3, 128, 128), (4, 3, 256, 256)]:
         x = synth_images(*shape).cuda()
-        g = net.graphed() if args.graph else None
+        g = net.graphed(check=args.check) if args.graph else None
         with torch.no_grad():
             fwd = (lambda: g(x)) if args.graph else (lambda: net(x))
             for _ in range(5):
@@ -37,7 +38,7 @@ def main():
                 out = fwd()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.iters
-        print(f"{'graph' if args.graph else 'eager'} {shape}: {dt * 1e3:7.3f} ms / forward  ({shape[0] / dt:7.1f} img/s)", flush=True)
+        print(f"{('graph/' + args.check) if args.graph else 'eager'} {shape}: {dt * 1e3:7.3f} ms / forward  ({shape[0] / dt:7.1f} img/s)", flush=True)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,25 @@ LDS_LAT = int(__import__('os').environ.get('WX4_LDS_LAT', '3'))    # slots betwe
 HEAD_CAP = 14  # slot 0 sits behind the barrier, in front of the first MFMA which waits for its fragments anyway
 S1_START = int(__import__("os").environ.get("WX4_S1_START", "8"))   # stage 1: first slot that touches the pixels requested in stage 0
 S1_START_PRE = int(__import__("os").environ.get("WX4_S1_START_PRE", "3"))   # ... when they are pre-activated first (more work to place)
+# MFMA order inside a row tap: "slab" = per slab the three products back to back (lo*hi, hi*lo, hi*hi: one accumulator, A changes once,
+# B every time); "part" = per product all slabs (B fragment constant over 2*NREP MFMAs, then NREP with the lo plane)
+ORDER = __import__("os").environ.get("WX4_ORDER", "slab")
+PART_SEQ = (0, 2, 1)
+
+
+def slot_mfma(s, nrep):
+    """slot -> (group g = dy*nrep + slab, part)"""
+    if ORDER == "slab":
+        return s // 3, s % 3
+    dy, t = divmod(s, 3 * nrep)
+    return dy * nrep + t % nrep, PART_SEQ[t // nrep]
+
+
+def first_use(g, nrep):
+    if ORDER == "slab":
+        return 3 * g
+    dy, nr = divmod(g, nrep)
+    return dy * 3 * nrep + nr
 
 
 class Op:
@@ -80,7 +99,7 @@ def build(nrep, ji, pre):
     for dy in range(3):
         reads.append(("rdB%d" % dy, "rdB(%s);" % I(dy), 3 * nrep * dy))
     for g in range(ng):
-        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), 3 * g))
+        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), first_use(g, nrep)))
     for name, code, use in sorted(reads, key=lambda r: r[2]):
         o = Op(name, code, 2, kind="ldsr")
         o.deadline = max(0, use - LDS_LAT)
@@ -152,7 +171,7 @@ def build_final(nrep, ji):
     for dy in range(3):
         reads.append(("rdB%d" % dy, "rdB(%s);" % I(dy), 3 * nrep * dy))
     for g in range(ng):
-        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), 3 * g))
+        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), first_use(g, nrep)))
     for name, code, use in sorted(reads, key=lambda r: r[2]):
         o = Op(name, code, 2, kind="ldsr")
         o.deadline = max(0, use - LDS_LAT)
@@ -217,7 +236,7 @@ def emit(nrep, ji, pre, out):
         here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])
         line = "  SB(); " + " ".join(o.code for o in here) + " SB();"
         if s < nm:
-            line += " mfma(%s, %s);" % (I(s // 3), I(s % 3))
+            line += " mfma(%s, %s);" % tuple(I(v) for v in slot_mfma(s, nrep))
             if s % 3 == 2:
                 line += " WX_TS(%d);" % (s // 3)          # (timing builds: s_memtime stamp behind every MFMA group)
         out.append(line + " \\")

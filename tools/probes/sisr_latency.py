@@ -25,7 +25,7 @@ for n in [int(a) for a in sys.argv[1:]] or [1, 16]:
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 50
     print(f"sisr x4 eager ({n}, 3, 64, 64) -> 256x256: {dt * 1e3:7.3f} ms / forward", flush=True)
-    g = net.graphed()
+    g = net.graphed(check=os.environ.get("GRAPH_CHECK", "sync"))
     with torch.no_grad():
         for _ in range(5):
             g(x, 4)

@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-configs $*"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- $BENCH --steps 5 --warmup 2 > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES GRBM_GUI_ACTIVE \
   --kernel-trace -d "$OUT/pmc_sq" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_sq.log" 2>&1
@@ -19,7 +19,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_B
   --kernel-trace -d "$OUT/pmc_sq2" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_write.log" 2>&1
-python $ROOT/tools/summarize_prof.py "$OUT" > "$OUT/summary.json" 2> "$OUT/summary.err"
-tail -3 "$OUT/trace.log"; cat "$OUT/summary.err" | tail -5; head -c 6000 "$OUT/summary.json"
+python $ROOT/tools/summarize_r04.py "$OUT" "$OUT" r04 > "$OUT/summary.txt" 2> "$OUT/summary.err"
+tail -3 "$OUT/trace.log"; tail -5 "$OUT/summary.err"; cat "$OUT/summary.txt"; cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"; find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 # keep gpurun_out small: drop the raw per-dispatch CSVs except the stats
 find "$OUT" -name "*counter_collection.csv" -size +8M -delete
