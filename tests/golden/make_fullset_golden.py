@@ -11,7 +11,8 @@ What BASELINE.json's metric names -- "PSNR parity CBSD68 sigma=50 / Set5 x4" -- 
 The networks are the reference's own classes (networks/VIRNet.py) with the deterministic synthetic state_dict the parity tests use
 (checkpoints are not shipped).  The JSON holds the reference's per-image PSNRs (and a few output statistics); the GPU
 tests run the HIP forward on the same inputs and must land within 0.01 dB per image and in the set means
-(tests/test_fullset_gpu.py).  The images are copied into tests/golden/{cbsd68,set5}/ (data files the reference's scripts read)."""
+(tests/test_fullset_gpu.py).  The images are copied into tests/golden/{cbsd68,cbsd68_rest,set5}/ (data files the reference's scripts read; cbsd68/ holds the 12 images
+the oracle-based tests walk, cbsd68_rest/ the other 56)."""
 import glob
 import json
 import os
@@ -51,11 +52,12 @@ def as_ubyte(a):            # skimage.img_as_ubyte on float images in [-1, 1]: c
 out = {}
 # ------------------------------------------------------------------ CBSD68, iid sigma = 50
 files = sorted(str(x) for x in glob.glob(os.path.join(REF, "test_data", "CBSD68", "*.png")))
-os.makedirs(os.path.join(HERE, "cbsd68"), exist_ok=True)
+os.makedirs(os.path.join(HERE, "cbsd68_rest"), exist_ok=True)      # (cbsd68/ keeps the 12 images the oracle-based tests walk)
 for f in files:
-    dst = os.path.join(HERE, "cbsd68", os.path.basename(f))
-    if not os.path.exists(dst):
-        shutil.copyfile(f, dst)
+    if not os.path.exists(os.path.join(HERE, "cbsd68", os.path.basename(f))):
+        dst = os.path.join(HERE, "cbsd68_rest", os.path.basename(f))
+        if not os.path.exists(dst):
+            shutil.copyfile(f, dst)
 cfg = dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=3, noise_cond=True, extra_mode="Input", noise_avg=False)
 net = VIRAttResUNet(**cfg)
 sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})

@@ -25,9 +25,10 @@ STEPS, BATCH, PATCH = 400, 16, 128
 
 
 def test_trained_like_checkpoint_hip_vs_oracle():
-    names = sorted(n for n in os.listdir(os.path.join(GOLDEN, "cbsd68")) if n.endswith(".png"))
-    train_names, test_names = names[4:], names[:3]
-    imgs = [torch.from_numpy(veval.img_as_float32(veval.imread_rgb_uint8(os.path.join(GOLDEN, "cbsd68", n))).transpose(2, 0, 1).copy()) for n in train_names]
+    test_names = sorted(n for n in os.listdir(os.path.join(GOLDEN, "cbsd68")) if n.endswith(".png"))[:3]
+    train_paths = sorted(os.path.join(GOLDEN, "cbsd68_rest", n) for n in os.listdir(os.path.join(GOLDEN, "cbsd68_rest")) if n.endswith(".png"))
+    assert len(train_paths) >= 50
+    imgs = [torch.from_numpy(veval.img_as_float32(veval.imread_rgb_uint8(p)).transpose(2, 0, 1).copy()) for p in train_paths]
     torch.manual_seed(1234)
     net = VIRAttResUNet(**CFG).cuda().train()              # torch's default init, as the reference's training starts from
     opt = torch.optim.Adam(net.parameters(), lr=2e-4)

@@ -113,8 +113,6 @@ def build(nrep, ji, pre):
             lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "p"] + [(d.name, 0) for d in dma], kind="vmem"))
         for b in range(6):
             lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "h"] + [("ldp5", 0)] + [(d.name, 0) for d in dma], kind="vmem"))
-        if pre == 2:
-            lds.append(Op("ldsft", "ldsft();", 4, [(d.name, 0) for d in dma], kind="vmem"))
         # the DMA pieces go first (they must be older than the pixel loads: the end-of-stage wait counts on it), one per slot from slot
         # 1 on; then whatever still reads the OLD pixels, then the loads -- the sooner they leave, the more of their latency stage 0
         # hides -- and the rest of the position work behind them
@@ -128,10 +126,14 @@ def build(nrep, ji, pre):
         # end-of-stage waits are visible to it: gen header), pre-activation first
         if pre >= 1:
             t0 = S1_START_PRE
+            sdeps = []
+            if pre == 2:      # SFT scale / shift of the chunk: read from the LDS table the prologue filled (no registers held across stages)
+                stg.append(Op("rdsft", "rdsft();", 3, earliest=max(0, t0 - 1), kind="ldsr2"))
+                sdeps = [("rdsft", 1)]
             for b in range(6):
-                stg.append(Op("pr%d" % b, "pr(%s);" % I(b), 6 if pre == 1 else 12, earliest=t0))
-            stg.append(Op("prHa", "prHa();", 6, earliest=t0))
-            stg.append(Op("prHb", "prHb();", 6, earliest=t0))
+                stg.append(Op("pr%d" % b, "pr(%s);" % I(b), 6 if pre == 1 else 12, sdeps, earliest=t0))
+            stg.append(Op("prHa", "prHa();", 6, sdeps, earliest=t0))
+            stg.append(Op("prHb", "prHb();", 6, sdeps, earliest=t0))
             pdeps = [("pr%d" % b, 1) for b in range(6)]
             hdeps = [("prHa", 1), ("prHb", 1)]
         else:
@@ -230,7 +232,7 @@ def emit(nrep, ji, pre, out):
     else:
         ops, nm = build(nrep, ji, pre)
     load = schedule(ops, nm)
-    order = {"ldsr": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
+    order = {"ldsr": 0, "ldsr2": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
     out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre) if pre is not None else "#define WX4_FINAL_%d_%d \\" % (nrep, ji))
     for s in range(nm + 1):
         here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])

@@ -100,17 +100,19 @@ def build(nrep, ji, pre):
             lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "p"], kind="vmem"))
         for b in range(6):
             lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [(r, 1) for r in rd if r[0] == "h"] + [("ldp5", 0)], kind="vmem"))
-        if pre == 2:
-            lds.append(Op("ldsft", "ldsft();", 4, kind="vmem"))
         first = [o for o in stg if o.name in rd]
         rest = [o for o in stg if o.name not in rd]
         ops += dma + first + lds + rest
     elif ji == 1:
         if pre >= 1:
             t0 = S1_START_PRE
+            sdeps = []
+            if pre == 2:      # SFT scale / shift of the chunk: read from the LDS table the prologue filled (no registers held across stages)
+                stg.append(Op("rdsft", "rdsft();", 3, earliest=max(0, t0 - 1), kind="ldsr2"))
+                sdeps = [("rdsft", 1)]
             for b in range(6):
-                stg.append(Op("pr%d" % b, "pr(%s);" % I(b), 6 if pre == 1 else 12, earliest=t0))
-            stg.append(Op("prH", "prH();", 6, earliest=t0))
+                stg.append(Op("pr%d" % b, "pr(%s);" % I(b), 6 if pre == 1 else 12, sdeps, earliest=t0))
+            stg.append(Op("prH", "prH();", 6, sdeps, earliest=t0))
             pdeps = [("pr%d" % b, 1) for b in range(6)]
             hdeps = [("prH", 1)]
         else:
@@ -230,7 +232,7 @@ def emit(nrep, ji, pre, out, x_stage0):
             ks = [np_ + x[0], x[0] + x[1], -1]          # (-1: the kernel's own end-of-loop wait)
     # loads of the epilogue's operand tile counted in K: the kernel subtracts them when the instantiation has no such tile
     es = [x[0], x[0] + x[1], 0] if (pre is None and ji == 2) else [0, 0, 0]
-    order = {"ldsr": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
+    order = {"ldsr": 0, "ldsr2": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
     out.append("#define WX4H_STAGE_%d_%d_%d \\" % (nrep, ji, pre) if pre is not None else "#define WX4H_FINAL_%d_%d \\" % (nrep, ji))
     for s in range(nm + 1):
         here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])

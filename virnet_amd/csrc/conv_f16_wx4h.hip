@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   char* const v_lds = smem;
   char* const w_lds = smem + WH_VBYTES;
   constexpr int LDS_MAIN = WH_VBYTES + 4 * GRP > 12 * WH_XBLK ? WH_VBYTES + 4 * GRP : 12 * WH_XBLK;
+  float* const sft_lds = reinterpret_cast<float*>(smem + LDS_MAIN) + 2 * NB;   // PRE 2: [in_mul | in_add] of the image's Cin channels
   float* const sb_lds = reinterpret_cast<float*>(smem + LDS_MAIN);   // [inverse scale | bias] of the NB channels
 
   // ---- workgroup -> (tile, channel block): contiguous tile ranges per XCD (block b runs on XCD b%8), channel blocks adjacent
@@ -112,6 +113,15 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
       sa = *reinterpret_cast<const f32x4*>(iadd + (ld_so >> 2) + 4 * sq);
       smh = imul[(ld_so >> 2) + hch];
       sah = iadd[(ld_so >> 2) + hch];
+    }
+  };
+  // K loop: the chunk's SFT vectors come from the LDS table the prologue filled, read at the point of use (stage 1)
+  auto rdsft = [&]() {
+    if constexpr (PRE == 2) {
+      sm = *reinterpret_cast<const f32x4*>(sft_lds + (ld_so >> 2) + 4 * sq);
+      sa = *reinterpret_cast<const f32x4*>(sft_lds + a.Cin + (ld_so >> 2) + 4 * sq);
+      smh = sft_lds[(ld_so >> 2) + hch];
+      sah = sft_lds[a.Cin + (ld_so >> 2) + hch];
     }
   };
   auto pr = [&](auto bc) {
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
     poff[i] = __builtin_amdgcn_readfirstlane((r >> 1) * (int)slab_bytes + jq * (3 * 6144) + (r & 1) * 1024);
     pdst[i] = __builtin_amdgcn_readfirstlane(qd * 1024);
   }
+  (void)wrs; (void)lane16;                          // (only the device pass uses them: the builtin below is compiled out of the host pass)
   auto dma_piece = [&](int i, int src_off, char* wb) {      // src_off = chunk * 36 KB + ji * 6 KB + dy * 2 KB
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(wb + pdst[i]), 16, lane16, src_off + poff[i], 0, 0);
@@ -269,6 +280,9 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   hP(WX_I(0)); hHi(); hSub(); hLo(); hSt(WX_I(0));
   hP(WX_I(1)); hHi(); hSub(); hLo(); hSt(WX_I(1));
   if (tid < 2 * NB) sb_lds[tid] = sbv;
+  if constexpr (PRE == 2) {
+    for (int i = tid; i < a.Cin; i += 256) { sft_lds[i] = imul[i]; sft_lds[a.Cin + i] = iadd[i]; }
+  }
   __syncthreads();
   TSTAMP(1);
 
@@ -513,7 +527,7 @@ int launch_wx4h_t(FArgs k, hipStream_t st) {
   static unsigned long long attr_done = 0;
   auto kern = conv_wx4h_kernel<NREP, EPI, PRE>;
   if (virnet::first_use_on_device(attr_done)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wx4h): %s", hipGetErrorString(e));
   }
   k.nty = (k.H + 7) / 8;
@@ -527,7 +541,9 @@ int launch_wx4h_t(FArgs k, hipStream_t st) {
   k.mg_ncb = div_magic(ncb);
   k.mg_ntx = div_magic(k.ntx);
   k.mg_tpi = div_magic(k.ntx * k.nty);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, st, k);
+  const int lds = LDS + (PRE == 2 ? 2 * k.Cin * 4 : 0);                          // (+ the image's SFT vectors)
+  if (lds > 80 * 1024 + 4096 && lds > 160 * 1024) return virnet::set_error("virnet_conv_wx4 (8-row tiles): %d input channels of SFT vectors do not fit LDS", k.Cin);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, k);
   return virnet::check_launch("conv_wx4h launch");
 }
 

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
       if (q >= 12) q -= 12;
       const int slab = q / 6, r = q - slab * 6;
       const int src = slab * KB_SLAB_BYTES + (s / 3) * (9 * 2048) + (s % 3) * 6144 + r * 1024;
+      (void)src; (void)wrs; (void)buf;
 #if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(buf + q * 1024), 16, lane16, src, 0, 0);
 #endif
