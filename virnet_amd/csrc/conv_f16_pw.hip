@@ -340,8 +340,12 @@ int virnet::launch_f16_convt(FArgs k, int cin_real, hipStream_t st) {
   k.Cin = (cin_real + 47) / 48 * 48;
   const int nchr = cin_real >> 4;
   int n6 = nb / 6, rem = nb - 6 * n6;
+  int max_group = 6;
+  if (const char* f = getenv("VIRNET_CONVT_SLABS")) max_group = atoi(f);      // tuning aid: largest slab group per workgroup (6 default, 3, 2)
+  if (max_group < 6) { n6 = 0; rem = nb; }
   if (rem == 1 && n6 >= 1) { n6 -= 1; rem = 7; }
   int n3 = rem / 3, rem2 = rem - 3 * n3;
+  if (max_group < 3) { n3 = 0; rem2 = rem; }
   if (rem2 == 1 && n3 >= 1) { n3 -= 1; rem2 = 4; }
   const int n2 = rem2 / 2, n1 = rem2 - 2 * n2;
   int base = 0;
