@@ -17,7 +17,8 @@ from virnet_amd.networks.params import ConvParam  # noqa: E402
 SHAPES = {"l0": (32, 256, 256, 96), "l1": (32, 128, 128, 192), "l2": (32, 64, 64, 288), "s64": (32, 256, 256, 64),
           "l0s": (64, 128, 128, 96), "one": (1, 484, 324, 96),
           "one1": (1, 242, 162, 192), "one2": (1, 121, 81, 288), "q0": (1, 256, 256, 96), "q1": (1, 128, 128, 192),
-          "q2": (1, 64, 64, 288), "r1": (1, 64, 64, 192), "r2": (1, 32, 32, 288), "r0": (1, 128, 128, 96), "b4": (4, 256, 256, 96), "b4_1": (4, 128, 128, 192), "b4_2": (4, 64, 64, 288), "t2": (32, 32, 32, 288), "t1": (32, 64, 64, 192)}
+          "q2": (1, 64, 64, 288), "r1": (1, 64, 64, 192), "r2": (1, 32, 32, 288), "r0": (1, 128, 128, 96), "b4": (4, 256, 256, 96), "b4_1": (4, 128, 128, 192), "b4_2": (4, 64, 64, 288), "t2": (32, 32, 32, 288), "t1": (32, 64, 64, 192),
+          "l1s": (64, 64, 64, 192), "l2s": (64, 32, 32, 288), "s0": (16, 256, 256, 96), "s1": (16, 128, 128, 160), "s2": (16, 64, 64, 224)}
 
 
 def main():

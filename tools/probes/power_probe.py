@@ -18,8 +18,10 @@ def main():
     cp = ConvParam(c, c, 3).cuda()
     x = torch.rand(n, h, w, c, device="cuda") - 0.5
     res = torch.rand(n, h, w, c, device="cuda") - 0.5
-    if os.environ.get("BENCH_ZEROS") == "1":
+    z = os.environ.get("BENCH_ZEROS", "0")       # 1: everything zero; x: zero activations, random weights; w: zero weights, random activations
+    if z in ("1", "x"):
         x.zero_(); res.zero_()
+    if z in ("1", "w"):
         with torch.no_grad():
             cp.weight.zero_(); cp.bias.zero_()
     kw = {"res": dict(res=res, want_raw=True), "pre": dict(in_slope=0.2, want_raw=False, want_act=True)}[a.mode]
