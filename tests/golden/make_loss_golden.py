@@ -27,9 +27,18 @@ sigma_gt = torch.from_numpy(g.random((2, 1, 9, 11), dtype=np.float32) * 0.05 + 1
 alpha0 = 0.5 * torch.tensor([7 ** 2], dtype=torch.float32)
 out = elbo_denoising_simple(mu, sigma, noisy, gt, 1e-6, alpha0, alpha0 * sigma_gt)
 out[0].backward()
-json.dump(dict(seed=[77, 1], shape=list(shape), eps2=1e-6, var_window=7, values=[float(v) for v in out],
-               dmu_sum=float(mu.grad.double().sum()), dmu_absmax=float(mu.grad.abs().max()),
-               dsigma_sum=float(sigma.grad.double().sum()), dsigma_absmax=float(sigma.grad.abs().max())),
+single = dict(values=[float(v) for v in out], dmu_sum=float(mu.grad.double().sum()), dmu_absmax=float(mu.grad.abs().max()),
+              dsigma_sum=float(sigma.grad.double().sum()), dsigma_absmax=float(sigma.grad.abs().max()))
+# list-valued mu (ELBO_simple.py:30-34,43-47): two more restorer outputs drawn from the same stream
+mu2 = torch.from_numpy(g.random(shape, dtype=np.float32)).requires_grad_(True)
+mu3 = torch.from_numpy(g.random(shape, dtype=np.float32)).requires_grad_(True)
+mu_l = mu.detach().clone().requires_grad_(True)
+sigma_l = sigma.detach().clone().requires_grad_(True)
+out_l = elbo_denoising_simple([mu_l, mu2, mu3], sigma_l, noisy, gt, 1e-6, alpha0, alpha0 * sigma_gt)
+out_l[0].backward()
+listed = dict(values=[float(v) for v in out_l], dmu_sums=[float(m.grad.double().sum()) for m in (mu_l, mu2, mu3)],
+              dsigma_sum=float(sigma_l.grad.double().sum()))
+json.dump(dict(seed=[77, 1], shape=list(shape), eps2=1e-6, var_window=7, list_case=listed, **single),
           open(os.path.join(HERE, "loss.json"), "w"), indent=1)
 print([float(v) for v in out])
 

@@ -30,6 +30,34 @@ def test_elbo_matches_reference():
     assert float(sigma.grad.abs().max()) == pytest.approx(ref["dsigma_absmax"], rel=1e-6)
 
 
+def test_elbo_list_valued_mu_matches_reference():
+    """ELBO_simple.py:30-34,43-47: ``mu`` may be a list of restorer outputs (averaged Gaussian KL and likelihood)."""
+    ref = json.load(open(os.path.join(GOLDEN, "loss.json")))
+    g = np.random.Generator(np.random.Philox(key=ref["seed"]))
+    shape = tuple(ref["shape"])
+    mu = torch.from_numpy(g.random(shape, dtype=np.float32)).requires_grad_(True)
+    sigma = torch.from_numpy((g.random((2, 1, 9, 11), dtype=np.float32) * 0.05 + 1e-3)).requires_grad_(True)
+    noisy = torch.from_numpy(g.random(shape, dtype=np.float32))
+    gt = torch.from_numpy(g.random(shape, dtype=np.float32))
+    sigma_gt = torch.from_numpy(g.random((2, 1, 9, 11), dtype=np.float32) * 0.05 + 1e-3)
+    mu2 = torch.from_numpy(g.random(shape, dtype=np.float32)).requires_grad_(True)
+    mu3 = torch.from_numpy(g.random(shape, dtype=np.float32)).requires_grad_(True)
+    alpha0 = 0.5 * torch.tensor([ref["var_window"] ** 2], dtype=torch.float32)
+    out = elbo_denoising_simple([mu, mu2, mu3], sigma, noisy, gt, ref["eps2"], alpha0, alpha0 * sigma_gt)
+    L = ref["list_case"]
+    for got, want in zip(out, L["values"]):
+        assert float(got) == pytest.approx(want, rel=1e-6)
+    out[0].backward()
+    for m, want in zip((mu, mu2, mu3), L["dmu_sums"]):
+        assert float(m.grad.double().sum()) == pytest.approx(want, rel=1e-5)
+    assert float(sigma.grad.double().sum()) == pytest.approx(L["dsigma_sum"], rel=1e-5)
+    one = elbo_denoising_simple([mu.detach()], sigma.detach(), noisy, gt, ref["eps2"], alpha0, alpha0 * sigma_gt)
+    for got, want in zip(one, ref["values"]):
+        assert float(got) == pytest.approx(want, rel=1e-6)          # a one-element list = the tensor form
+    with pytest.raises(ValueError):
+        elbo_denoising_simple([], sigma, noisy, gt, ref["eps2"], alpha0, alpha0 * sigma_gt)
+
+
 @pytest.mark.parametrize("down", ["Bicubic", "Direct"])
 def test_elbo_sisr_matches_reference_golden(down):
     """virnet_amd.loss.elbo_sisr against the reference's loss/ELBO_simple.py::elbo_sisr (tests/golden/loss_sisr.json, produced by

@@ -29,14 +29,23 @@ def likelihood(x: Tensor, mu_q: Tensor, var_q: float, alpha_q: Tensor, beta_q: T
     return (0.5 * (beta_q.log() - torch.digamma(alpha_q) + alpha_q / beta_q * ((x - mu_q) ** 2 + var_q))).mean() + 0.5 * log(2 * pi)
 
 
-def elbo_denoising_simple(mu: Tensor, sigma_est: Tensor, im_noisy: Tensor, im_gt: Tensor, eps2: float, alpha0: Tensor,
+def elbo_denoising_simple(mu, sigma_est: Tensor, im_noisy: Tensor, im_gt: Tensor, eps2: float, alpha0: Tensor,
                           beta0: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-    """(loss, lh, kl_gauss, kl_Igamma) for a single-tensor ``mu`` (ELBO_simple.py:23-53; alpha0 = 0.5*var_window**2 and
-    beta0 = alpha0*sigma_gt come from train_denoising_syn.py:157,172)."""
-    klg = kl_gauss(mu, im_gt, eps2)
+    """(loss, lh, kl_gauss, kl_Igamma) (ELBO_simple.py:23-53; alpha0 = 0.5*var_window**2 and beta0 = alpha0*sigma_gt come from
+    train_denoising_syn.py:157,172).  ``mu`` is the restorer's output or, as the reference allows (:30-34,43-47), a LIST of outputs
+    (deep supervision): the Gaussian KL and the likelihood are then averaged over the list, the variance term is shared."""
+    mus = list(mu) if isinstance(mu, (list, tuple)) else [mu]
+    if not mus:
+        raise ValueError("elbo_denoising_simple: empty list of restorer outputs")
     beta = sigma_est * alpha0
     klig = kl_inverse_gamma(beta, alpha0 - 1, beta0)
-    lh = likelihood(im_noisy, mu, eps2, alpha0 - 1, beta)
+    klg = kl_gauss(mus[0], im_gt, eps2)
+    lh = likelihood(im_noisy, mus[0], eps2, alpha0 - 1, beta)
+    for m in mus[1:]:
+        klg = klg + kl_gauss(m, im_gt, eps2)
+        lh = lh + likelihood(im_noisy, m, eps2, alpha0 - 1, beta)
+    if len(mus) > 1:
+        klg, lh = klg / len(mus), lh / len(mus)
     return lh + klg + klig, lh, klg, klig
 
 
