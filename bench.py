@@ -461,6 +461,9 @@ def main():
                     "traffic_source": ("profiles/pmc_latest.json (%s)" % (pmc or {}).get("source", "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes")
                                        if (pmc or {}).get("form", "wino") == form else None),
                     "kernel": kern, "algorithm": how,
+                    "ceiling_note": ("the launch group runs the socket at its package power cap (see `power`: mean W of the timed region against cap_w; "
+                                     "profiles/r04_probes.md: 1399-1400 W of 1400 W on this kernel alone, 2.4 GHz and 16 % less time on all-zero operands) -- "
+                                     "frac is bounded by joules per MFMA on this data, not by issue slots"),
                     "algorithmic_tflops": round(algorithmic, 2), "executed_per_algorithmic_flop": round(factor, 4),
                     "algorithmic_over_fp32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
                     "launches_per_step": d["launches"] // args.steps,
