@@ -141,7 +141,8 @@ int virnet_conv_f16(const virnet_conv_desc* d, void* stream);
  *     bias / single-store epilogue only (csrc/conv_f16_s2.hip);
  *   - ks = 1, epi = VIRNET_EPI_CONVT (UpBlock.upsampler + bridge add, AttResUNet.py:80,84-87): `wpack` from
  *     virnet_pack_f16_convt_weight (the IOHW [cin][cout][2][2] tensor as the pointwise GEMM to rows (a*2+b)*cout + co, contraction
- *     zero-padded to a multiple of 48), n_pad = 4*cout, bias + `res` (bridge) / single-store epilogue (csrc/conv_f16_pw.hip). */
+ *     kept as is when cin is a multiple of 32 -- K then runs in 2-chunk stages with two workgroups per CU -- else zero-padded to a
+ *     multiple of 48: virnet_f16_convt_weight_floats sizes it), n_pad = 4*cout, bias + `res` (bridge) / single-store epilogue (csrc/conv_f16_pw.hip). */
 /* bf16-OPERAND variant of the stride-1 3x3 NHWC convolution (BASELINE configs[4]'s training precision; reduced accuracy, ~4e-3 per
  * operand): ONE v_mfma_f32_32x32x16_bf16 per k-step, operands rounded to bf16 (activations while staged, weights when packed), fp32
  * accumulation, bias / mask / residual / activation in fp32.  Same descriptor; `wpack` from virnet_pack_bf16_weight (same size and

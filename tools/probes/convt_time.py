@@ -11,8 +11,12 @@ for (n, h, w, cin, cout) in [(32, 128, 128, 192, 96), (32, 64, 64, 288, 192), (1
     br = torch.rand(n, 2 * h, 2 * w, cout, device="cuda") - 0.5
     pw = cp.packed()
     ref = None
-    for form in ("6", "3", "2"):
-        os.environ["VIRNET_CONVT_SLABS"] = form
+    for form in ("ks2", "ks3", "2"):
+        os.environ.pop("VIRNET_CONVT_SLABS", None); os.environ.pop("VIRNET_CONVT_KS", None)
+        if form == "ks3":
+            os.environ["VIRNET_CONVT_KS"] = "3"
+        elif form != "ks2":
+            os.environ["VIRNET_CONVT_SLABS"] = form
         for _ in range(3):
             y, _ = ops.conv_mfma(x, pw, res=br, want_raw=True)
         if ref is None:
@@ -25,4 +29,4 @@ for (n, h, w, cin, cout) in [(32, 128, 128, 192, 96), (32, 64, 64, 288, 192), (1
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         gb = (n * h * w * cin * 4 + 2 * n * 4 * h * w * cout * 4) / 1e9
-        print(f"convT {cin}->{cout} @{h}x{w} x{n}  slabs<= {form}: median {ts[10]:.3f} ms  min {ts[0]:.3f}   {gb / ts[10]:.2f} TB/s", flush=True)
+        print(f"convT {cin}->{cout} @{h}x{w} x{n}  form {form}: median {ts[10]:.3f} ms  min {ts[0]:.3f}   {gb / ts[10]:.2f} TB/s", flush=True)

@@ -17,17 +17,20 @@
 namespace {
 using namespace virnet;
 
-template <int NG, int NREP>
-__global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a, const int nchr /* real 16-channel chunks */, const long npix) {
+// KS = 16-channel chunks per K stage.  3 (round 2): 120 KB of LDS at 6 slabs, ONE workgroup per CU.  2 (round 4): 80 KB and <= 128
+// VGPRs, so TWO workgroups share a CU -- the K loop is only Cin/32 stages and the epilogue moves 300 KB per workgroup, so a lone
+// workgroup serialises latencies (profiles/r04_probes.md 5); with two, one's epilogue runs beside the other's loads and MFMAs.
+template <int NG, int NREP, int KS>
+__global__ __launch_bounds__(256 * NG, KS == 2 ? 2 * NG : NG) void conv_f16_pw_kernel(const FArgs a, const int nchr /* real 16-channel chunks */, const long npix) {
   constexpr int NT = 256 * NG, NWAVES = 4 * NG;
   constexpr int TP = 128;                              // pixels per workgroup
-  constexpr int PLANE = TP * 32, KC = 2 * PLANE, XB = 3 * KC;
-  constexpr int NPIECE = 3 * TP * 2;
+  constexpr int PLANE = TP * 32, KC = 2 * PLANE, XB = KS * KC;
+  constexpr int NPIECE = KS * TP * 2;
   constexpr int PPT = (NPIECE + NT - 1) / NT;          // 2 (8 waves) or 3 (4 waves)
   static_assert((PPT - 1) * NT <= NPIECE, "surplus threads redo piece k-1");
   constexpr int SLABS = NG * NREP;
-  constexpr int WGRP = 3 * SLABS * 2048;
-  constexpr int NDMA = 3 * SLABS * 2;
+  constexpr int WGRP = KS * SLABS * 2048;
+  constexpr int NDMA = KS * SLABS * 2;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const x_lds = smem;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pb = wv & 3, sg = wv >> 2;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int nst = a.Cin / 48;                           // stages (Cin here = the PADDED contraction length)
+  const int nst = a.Cin / (16 * KS);                    // stages (Cin here = the PADDED contraction length, a multiple of 16 * KS)
   const int cx = nchr * 16;                             // channels of x
 
   // ---- pixel staging: piece -> (chunk-in-stage kc, pixel, half)
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     *reinterpret_cast<h8*>(xb + PLANE + sdst[k]) = lo;
   };
   auto stage_src = [&](int stage, int k) -> const float* {
-    const int chunk = min(stage * 3 + skc[k], nchr - 1);             // padded chunks re-read a valid one (their weights are zero)
+    const int chunk = min(stage * KS + skc[k], nchr - 1);            // padded chunks re-read a valid one (their weights are zero)
     return a.x + soff[k] + chunk * 16;
   };
 
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
       const int qd = i * NWAVES + wv;
       if (qd < NDMA) {
         const int tg = qd / (SLABS * 2), rem = qd - tg * (SLABS * 2);
-        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * 3 + tg) * 2 + (rem & 1)) * 1024);
+        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * KS + tg) * 2 + (rem & 1)) * 1024);
       }
     }
   };
@@ -150,12 +153,12 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
       s0[k] = *reinterpret_cast<const f32x4*>(src);
       s1[k] = *reinterpret_cast<const f32x4*>(src + 4);
     }
-    read_ab(wb, xb, 0, P);                                  // (register set: stage parity + k-step; three k-steps per stage)
+    read_ab(wb, xb, 0, KS == 3 ? P : 0);                    // (register set: KS 3: stage parity + k-step; KS 2: the k-step)
 #pragma unroll
-    for (int kc = 0; kc < 3; ++kc) {
-      const int cur = (P + kc) & 1;
+    for (int kc = 0; kc < KS; ++kc) {
+      const int cur = KS == 3 ? (P + kc) & 1 : kc & 1;
       SB();
-      if (kc < 2) {
+      if (kc < KS - 1) {
         read_ab(wb, xb, kc + 1, cur ^ 1);
       } else {
 #pragma unroll
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
           acc[nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[nr], 0, 0, 0);
         }
       constexpr int NM = 3 * NREP;
-      if (kc < 2) {
+      if (kc < KS - 1) {
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -222,7 +225,8 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     pbase[it] = ((im * 2 * a.H + 2 * yy) * W2 + 2 * xx) * (long)C;
   }
   const int row0 = (a.slab_base + cb * SLABS + sg * NREP) * 32;       // first GEMM row of this wave
-  f32x4 bias4[NREP], inv4[NREP], rv[NREP][NIT];
+  constexpr bool RV_ALL = KS == 3;                       // KS 2 (128 VGPRs): the bridge values of ONE slab at a time
+  f32x4 bias4[NREP], inv4[NREP], rv[RV_ALL ? NREP : 1][NIT];
   long eo[NREP];
 #pragma unroll
   for (int nr = 0; nr < NREP; ++nr) {
@@ -231,9 +235,11 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     eo[nr] = ((long)(ab >> 1) * W2 + (ab & 1)) * C + co;
     inv4[nr] = *reinterpret_cast<const f32x4*>(a.inv_scale + nrow + cq * 4);
     bias4[nr] = *reinterpret_cast<const f32x4*>(bp + co);
+    if (RV_ALL || nr == 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      rv[nr][it] = has_res ? *reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int it = 0; it < NIT; ++it)
+        rv[RV_ALL ? nr : 0][it] = has_res ? *reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   auto turn_in = [&](int nr, int region) {
 #pragma unroll
@@ -246,8 +252,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
 #pragma unroll
   for (int nr = 0; nr < NREP; ++nr) {
     asm volatile("" ::"v"(inv4[nr]), "v"(bias4[nr]));
+    if (RV_ALL || nr == 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) asm volatile("" ::"v"(rv[nr][it]));
+      for (int it = 0; it < NIT; ++it) asm volatile("" ::"v"(rv[RV_ALL ? nr : 0][it]));
+    }
   }
 #endif
 #pragma unroll
@@ -257,19 +265,28 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_pw_kernel(const FArgs a
     f32x4 tv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) tv[it] = *reinterpret_cast<const f32x4*>(tbuf + (nr & 1) * TREG + (it * 8 + psub) * TPIX + cq * 16);
+    f32x4 ov[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const f32x4 v = lrelu4(tv[it] * inv4[nr] + b4 + rv[nr][it], slope_eff);
-      if (pok[it]) *reinterpret_cast<f32x4*>(y + pbase[it] + eo[nr]) = v;
+    for (int it = 0; it < NIT; ++it) ov[it] = lrelu4(tv[it] * inv4[nr] + b4 + rv[RV_ALL ? nr : 0][it], slope_eff);
+    if (!RV_ALL && nr + 1 < NREP) {                      // next slab's bridge values: requested before this slab's stores (one vmcnt)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        rv[0][it] = has_res ? *reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr + 1]) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (pok[it]) *reinterpret_cast<f32x4*>(y + pbase[it] + eo[nr]) = ov[it];
   }
 }
 
-template <int NG, int NREP>
+template <int NG, int NREP, int KS = 3>
 int launch(FArgs k, int nchr, hipStream_t st) {
-  constexpr int LDS = 2 * (3 * 2 * 128 * 32) + 2 * (3 * NG * NREP * 2048);
+  constexpr int LDS_K = 2 * (KS * 2 * 128 * 32) + 2 * (KS * NG * NREP * 2048);
+  constexpr int LDS_E = 4 * NG * 2 * 32 * 144;                            // the waves' turn-around regions
+  constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
+  static_assert(KS == 3 || LDS <= 80 * 1024, "KS 2: two workgroups per CU");
   static unsigned long long attr_done = 0;
-  auto kern = conv_f16_pw_kernel<NG, NREP>;
+  auto kern = conv_f16_pw_kernel<NG, NREP, KS>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16_pw): %s", hipGetErrorString(e));
@@ -319,15 +336,19 @@ __global__ void pack_f16_convt_kernel(const float* __restrict__ w, int cout, int
 
 }  // namespace
 
+// padded contraction length of the weight image: the kernel walks K in stages of two 16-channel chunks when the channel count allows
+// (two workgroups per CU), of three otherwise
+static int convt_kpad(int cin) { return cin % 32 == 0 ? cin : (cin + 47) / 48 * 48; }
+
 extern "C" size_t virnet_f16_convt_weight_floats(int cin, int cout) {
-  const size_t k_pad = (size_t)(cin + 47) / 48 * 48, n_pad = (size_t)4 * cout;
+  const size_t k_pad = (size_t)convt_kpad(cin), n_pad = (size_t)4 * cout;
   return n_pad + n_pad * k_pad;
 }
 
 extern "C" int virnet_pack_f16_convt_weight(const float* w_iohw, int cout, int cin, float* packed, void* stream) {
   VIRNET_REQUIRE(w_iohw && packed, "virnet_pack_f16_convt_weight: NULL pointer");
   VIRNET_REQUIRE(cout > 0 && cout % 32 == 0 && cin > 0, "virnet_pack_f16_convt_weight: cout=%d must be a positive multiple of 32 (cin=%d)", cout, cin);
-  const int k_pad = (cin + 47) / 48 * 48, n_pad = 4 * cout;
+  const int k_pad = convt_kpad(cin), n_pad = 4 * cout;
   hipLaunchKernelGGL(pack_f16_convt_kernel, dim3((unsigned)n_pad), dim3(256), 0, static_cast<hipStream_t>(stream), w_iohw, cout, cin, k_pad,
                      n_pad, packed, reinterpret_cast<char*>(packed + n_pad));
   return virnet::check_launch("pack_f16_convt launch");
@@ -337,9 +358,12 @@ extern "C" int virnet_pack_f16_convt_weight(const float* w_iohw, int cout, int c
 // up-sampled tensor), slope; cin_real = channels of x.
 int virnet::launch_f16_convt(FArgs k, int cin_real, hipStream_t st) {
   const int nb = 4 * k.cout / 32;
-  k.Cin = (cin_real + 47) / 48 * 48;
+  k.Cin = convt_kpad(cin_real);
   const int nchr = cin_real >> 4;
   int n6 = nb / 6, rem = nb - 6 * n6;
+  // 2-chunk stages / two workgroups per CU for the 6-slab groups when the padded contraction length allows (VIRNET_CONVT_KS=3: round 2's form)
+  const char* const ks_env = getenv("VIRNET_CONVT_KS");
+  const bool ks2 = k.Cin % 32 == 0 && !(ks_env && atoi(ks_env) == 3 && k.Cin % 48 == 0);
   int max_group = 6;
   if (const char* f = getenv("VIRNET_CONVT_SLABS")) max_group = atoi(f);      // tuning aid: largest slab group per workgroup (6 default, 3, 2)
   if (max_group < 6) { n6 = 0; rem = nb; }
@@ -355,10 +379,10 @@ int virnet::launch_f16_convt(FArgs k, int cin_real, hipStream_t st) {
     kk.slab_base = base;
     kk.NP = groups * ng * nrep * 32;
     base += groups * ng * nrep;
-    if (ng == 2 && nrep == 3) return launch<2, 3>(kk, nchr, st);
-    if (ng == 1 && nrep == 3) return launch<1, 3>(kk, nchr, st);
-    if (ng == 1 && nrep == 2) return launch<1, 2>(kk, nchr, st);
-    return launch<1, 1>(kk, nchr, st);
+    if (ng == 2 && nrep == 3) return ks2 ? launch<2, 3, 2>(kk, nchr, st) : launch<2, 3>(kk, nchr, st);
+    if (ng == 1 && nrep == 3) return ks2 ? launch<1, 3, 2>(kk, nchr, st) : launch<1, 3>(kk, nchr, st);
+    if (ng == 1 && nrep == 2) return ks2 ? launch<1, 2, 2>(kk, nchr, st) : launch<1, 2>(kk, nchr, st);
+    return ks2 ? launch<1, 1, 2>(kk, nchr, st) : launch<1, 1>(kk, nchr, st);
   };
   if (int rc = run(2, 3, n6)) return rc;
   if (int rc = run(1, 3, n3)) return rc;
