@@ -266,6 +266,22 @@ int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float
                    int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream);
 int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
                           int bf16, void* stream);
+/* The weight gradients of the two stride-2 layers on the same kernel (backward of DownBlock.downsampler networks/AttResUNet.py:67 and
+ * UpBlock.upsampler :80).  The HIGH-resolution operand [n][h][w][c] (c % 32 == 0, w even) is re-laid by virnet_chsplit_s2 into a
+ * column-phase T: one row per source row, [h+2][2*c/32 blocks][hi|lo][seg(w/2)][32 ch][8 px], block par*c/32 + k = the pixels
+ * x = 2*ox + par of channel block k -- every tap of a stride-2 window is then an aligned 16-pixel run (or one shifted by a single T
+ * pixel), and a step of the contraction (low-res row oy) reads the high-res rows 2oy-1 .. 2oy+1: two new ring rows per step.
+ * The LOW-resolution operand [n][oh][ow][clo] is a plain virnet_chsplit T.
+ *   mode 0: 3x3 stride-2 pad-1 conv, hi = the conv's input (cin real channels), lo = its output gradient (cout): dw[cout][cin][3][3]
+ *   mode 1: 2x2 stride-2 transposed conv, hi = its output gradient (cout), lo = its input (cin):              dw[cin][cout][2][2]
+ * dw is overwritten (fixed summation order: bitwise reproducible); scratch = virnet_conv_wgrad_f16_s2_scratch_bytes() bytes. */
+size_t virnet_chsplit_s2_bytes(int n, int h, int w, int c);
+size_t virnet_chsplit_s2_colsum_bytes(int n, int h, int w, int c);
+int virnet_chsplit_s2(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                      int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream);
+size_t virnet_conv_wgrad_f16_s2_scratch_bytes(int n, int oh, int ow, int chi, int clo);
+int virnet_conv_wgrad_f16_s2(const void* hi_t, const void* lo_t, float* dw, float* scratch, int n, int oh, int ow, int chi, int clo,
+                             int cin, int cout, int mode, int bf16, void* stream);
 /* Backward of the SFT pre-activation a = lrelu(x*mul + add, slope) with per-image [n][c] vectors (AttResUNet.py:54-58), given da = dL/da:
  * du = da * lrelu'(x*mul+add);  dx = du*mul (+ res, the skip gradient, may be NULL);  dmul[n][c] += sum_p du*x;  dadd[n][c] += sum_p du
  * (zero dmul / dadd first).  NHWC tensors of n images x hw pixels x c channels (c % 4 == 0). */

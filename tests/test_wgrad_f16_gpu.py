@@ -142,3 +142,126 @@ def test_wgrad_f16_full_size_against_the_fp32_kernel(n, h, w, c, monkeypatch):
     scale = float(dw32.abs().max())
     assert float((dw - dw32).abs().max()) <= 3e-5 * scale
     assert float((db - db32).abs().max()) <= 3e-5 * float(db32.abs().max())
+
+
+# ---- the stride-2 layers on the same kernel (S = 2): DownBlock.downsampler AttResUNet.py:67, UpBlock.upsampler :80 -----------------------
+@pytest.mark.parametrize("bf16", [0, 1])
+def test_chsplit_s2_layout_is_exact(bf16):
+    """Column-phase T: block par*cb + k of row r holds the pixels x = 2*ox + par of source block k, pixel ox at index ox + 8."""
+    n, h, w, c = 2, 6, 74, 64
+    x = rnd(n, c, h, w, seed=350)
+    lib = nat.load()
+    nbytes = lib.virnet_chsplit_s2_bytes(n, h, w, c)
+    nseg, cb = _nseg(w // 2), c // 32
+    assert nbytes == n * (h + 2) * 2 * cb * 2 * nseg * 512
+    out = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+    xd = nhwc(x)
+    nat.check(lib.virnet_chsplit_s2(nat.ptr(xd), n, h, w, c, 1, 0.2, None, None, bf16, nat.ptr(out), None, None, 0, nat.stream_handle()), "chsplit_s2")
+    t = out.cpu().numpy().view(np.uint16).reshape(n, h + 2, 2 * cb, 2, nseg, 32, 8)
+    a = F.leaky_relu(x, 0.2)
+    if bf16:
+        planes = [a.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)]
+    else:
+        hi16 = a.to(torch.float16)
+        lo16 = (a - hi16.float()).to(torch.float16)
+        planes = [hi16.view(torch.int16).numpy().view(np.uint16), lo16.view(torch.int16).numpy().view(np.uint16)]
+    for p, ref in enumerate(planes):
+        exp = np.zeros((n, h + 2, 2 * c, nseg * 8), np.uint16)
+        for par in range(2):
+            exp[:, 1:h + 1, par * c:(par + 1) * c, 8:8 + w // 2] = ref[:, :, :, par::2].transpose(0, 2, 1, 3)
+        got = t[:, :, :, p].transpose(0, 1, 2, 4, 3, 5).reshape(n, h + 2, 2 * c, nseg * 8)
+        same = (got == exp) | ((got & 0x7FFF) == 0) & ((exp & 0x7FFF) == 0)
+        assert same.all(), f"plane {p}: {int((~same).sum())} elements differ"
+
+
+S2_SHAPES = [  # cin, cout, h, w (input), n
+    (96, 192, 10, 128, 1),     # minimum ring height; exactly one 64-pixel strip of outputs
+    (96, 192, 14, 130, 2),     # second strip one output pixel wide
+    (192, 288, 16, 64, 2),     # 32-column outputs: 32-pixel steps (six-wave workgroups), nine output blocks = three groups
+    (32, 64, 12, 20, 3),       # two output blocks, narrow
+    (160, 96, 22, 300, 1),     # three strips, five input blocks per phase
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", S2_SHAPES)
+def test_wgrad_f16_stride2_conv_vs_autograd(cin, cout, h, w, n):
+    x, dy = rnd(n, cin, h, w, seed=360), rnd(n, cout, h // 2, w // 2, seed=361)
+    wt = rnd(cout, cin, 3, 3, seed=362) * 0.1
+    _, dw_ref, db_ref = autograd_conv(x, wt, torch.zeros(cout), dy, stride=2, in_slope=0.2)
+    assert ops._wgrad_s2_ok(h // 2, cin)
+    dw, db = ops.conv_wgrad(nhwc(x), nhwc(dy), (cout, cin, 3, 3), stride=2, in_slope=0.2, bias_channels=cout)
+    assert relerr(dw.cpu(), dw_ref) <= TOL, relerr(dw.cpu(), dw_ref)
+    assert relerr(db.cpu(), db_ref) <= TOL, relerr(db.cpu(), db_ref)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,n", [(192, 96, 5, 64, 1), (192, 96, 9, 65, 2), (288, 192, 8, 32, 2), (64, 32, 7, 10, 3), (160, 96, 11, 150, 1)])
+def test_convt_backward_f16_vs_autograd(cin, cout, h, w, n):
+    """UpBlock.upsampler: weight + bias gradient on the f16 pipe from the high-res gradient, input gradient on the stride-2 conv kernel."""
+    from test_ops_gpu import make_conv, maxerr, nchw
+    cp = make_conv(cin, cout, ks=2, stride=2, transposed=True)
+    x = rnd(n, cin, h, w, seed=370).requires_grad_(True)
+    wt = cp.weight.detach().clone().requires_grad_(True)
+    bt = torch.zeros(cout, requires_grad=True)
+    dy = rnd(n, cout, 2 * h, 2 * w, seed=371)
+    F.conv_transpose2d(x, wt, bt, stride=2).backward(dy)
+    cp.cuda()
+    assert ops._wgrad_s2_ok(h, cout)
+    dw, db = ops.convt_wgrad(nhwc(x.detach()), nhwc(dy), tuple(cp.weight.shape))
+    assert relerr(dw.cpu(), wt.grad) <= TOL, relerr(dw.cpu(), wt.grad)
+    assert relerr(db.cpu(), bt.grad) <= TOL, relerr(db.cpu(), bt.grad)
+    pw = ops.pack_weight(cp.weight, None, transposed=True, dgrad=True)
+    assert pw.s2 is not None and pw.s2.f16 is not None
+    dx = ops.convt_dgrad(nhwc(dy), pw)
+    assert maxerr(nchw(dx), x.grad) <= TOL, maxerr(nchw(dx), x.grad)
+
+
+def test_wgrad_f16_stride2_reproducible_and_close_to_the_fp32_kernels(monkeypatch):
+    n = 4
+    x, dy = rnd(n, 96, 48, 140, seed=380), rnd(n, 192, 24, 70, seed=381)
+    xd, dyd = nhwc(x), nhwc(dy)
+    a, ab = ops.conv_wgrad(xd, dyd, (192, 96, 3, 3), stride=2, bias_channels=192)
+    b, bb = ops.conv_wgrad(xd, dyd, (192, 96, 3, 3), stride=2, bias_channels=192)
+    assert torch.equal(a, b)
+    xl, dyh = nhwc(rnd(n, 192, 24, 70, seed=382)), nhwc(rnd(n, 96, 48, 140, seed=383))
+    c, cb = ops.convt_wgrad(xl, dyh, (192, 96, 2, 2))
+    d, _ = ops.convt_wgrad(xl, dyh, (192, 96, 2, 2))
+    assert torch.equal(c, d)
+    monkeypatch.setenv("VIRNET_WGRAD_FORM", "f32")
+    assert not ops._wgrad_s2_ok(24, 96)
+    a32, ab32 = ops.conv_wgrad(xd, dyd, (192, 96, 3, 3), stride=2, bias_channels=192)
+    c32, cb32 = ops.convt_wgrad(xl, dyh, (192, 96, 2, 2))
+    assert relerr(a.cpu(), a32.cpu()) <= TOL and relerr(ab.cpu(), ab32.cpu()) <= TOL
+    assert relerr(c.cpu(), c32.cpu()) <= TOL and relerr(cb.cpu(), cb32.cpu()) <= TOL
+
+
+def test_wgrad_f16_stride2_bf16_variant(monkeypatch):
+    monkeypatch.setenv("VIRNET_CONV_FORM", "bf16")
+    cin, cout, h, w, n = 96, 192, 20, 136, 2
+    x, dy = rnd(n, cin, h, w, seed=390), rnd(n, cout, h // 2, w // 2, seed=391)
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(x.to(torch.bfloat16).float(), wt, None, stride=2, padding=1).backward(dy.to(torch.bfloat16).float())
+    dw = ops.conv_wgrad(nhwc(x), nhwc(dy), (cout, cin, 3, 3), stride=2)
+    assert relerr(dw.cpu(), wt.grad) <= TOL
+    xl, dyh = rnd(n, cout, h // 2, w // 2, seed=392), rnd(n, cin, h, w, seed=393)
+    wtt = torch.zeros(cout, cin, 2, 2, requires_grad=True)
+    F.conv_transpose2d(xl.to(torch.bfloat16).float().requires_grad_(False), wtt, None, stride=2).backward(dyh.to(torch.bfloat16).float())
+    dwt, dbt = ops.convt_wgrad(nhwc(xl), nhwc(dyh), (cout, cin, 2, 2))
+    assert relerr(dwt.cpu(), wtt.grad) <= TOL
+    assert relerr(dbt.cpu(), dyh.sum((0, 2, 3))) <= TOL
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(32, 128, 128, 96, 192), (32, 64, 64, 192, 288)])
+def test_wgrad_f16_stride2_full_size_against_the_fp32_kernels(n, h, w, cin, cout, monkeypatch):
+    """configs[4]'s stride-2 layer shapes: the f16-pipe forms against the round-1 fp32 kernels on the same device tensors."""
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(n, h, w, cin, device="cuda", generator=g) - 0.5
+    dy = (torch.rand(n, h // 2, w // 2, cout, device="cuda", generator=g) - 0.5) * 0.1
+    dw, db = ops.conv_wgrad(x, dy, (cout, cin, 3, 3), stride=2, bias_channels=cout)
+    xl = torch.rand(n, h // 2, w // 2, cout, device="cuda", generator=g) - 0.5
+    dyh = (torch.rand(n, h, w, cin, device="cuda", generator=g) - 0.5) * 0.1
+    dwt, dbt = ops.convt_wgrad(xl, dyh, (cout, cin, 2, 2))
+    monkeypatch.setenv("VIRNET_WGRAD_FORM", "f32")
+    dw32, db32 = ops.conv_wgrad(x, dy, (cout, cin, 3, 3), stride=2, bias_channels=cout)
+    dwt32, dbt32 = ops.convt_wgrad(xl, dyh, (cout, cin, 2, 2))
+    for got, ref in ((dw, dw32), (db, db32), (dwt, dwt32), (dbt, dbt32)):
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max())

@@ -125,6 +125,13 @@ SYMBOLS = [
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     ("virnet_conv_wgrad_f16", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]),
+    ("virnet_chsplit_s2_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_chsplit_s2_colsum_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_chsplit_s2", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("virnet_conv_wgrad_f16_s2_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("virnet_conv_wgrad_f16_s2", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_zero_stuff2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_space_to_depth2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

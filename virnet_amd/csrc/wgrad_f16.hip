@@ -29,6 +29,9 @@ struct TGeom {
   int n, h, w, c;      // source tensor (c = stored channels)
   int cb;              // 32-channel blocks of T
   int nseg;            // 8-pixel segments per row of T
+  int par2;            // column-phase mode (stride-2 layers): the source is [n][h][2w][c]; T has 2*ceil(c/32) blocks per row, block
+                       // par*cb/2 + k holding the pixels x = 2*ox + par of source block k (T pixel ox), so that the taps of a stride-2
+                       // window are aligned (even columns) or shifted by one T pixel (odd columns)
 };
 
 // segments per row of T: the pixels rounded up to whole steps (64 pixels; 32 for images of at most 32 columns) + one pad segment each side
@@ -50,7 +53,10 @@ __global__ __launch_bounds__(256) void chsplit_kernel(const float* __restrict__ 
   const int img = b / (g.h + 2);
   const int tid = threadIdx.x;
   const int q = tid & 7;                                 // channel quad
-  const int c0 = cb * 32 + q * 4;
+  const int cbh = g.par2 ? g.cb / 2 : g.cb;              // source channel blocks
+  const int par = g.par2 ? cb / cbh : 0;
+  const int c0 = (cb - par * cbh) * 32 + q * 4;
+  const int sw = g.par2 ? 2 * g.w : g.w;                 // source row length in pixels
   const float slope = in_act ? in_slope : 1.f;
   f32x4 m4 = f32x4{1.f, 1.f, 1.f, 1.f}, a4 = f32x4{0.f, 0.f, 0.f, 0.f};
   if (in_mul && c0 < g.c) {
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void chsplit_kernel(const float* __restrict__ 
     const bool ok = prow >= 1 && prow <= g.h && px >= 0 && px < g.w && c0 < g.c;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ok) {
-      v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + (prow - 1)) * g.w + px) * g.c + c0);
+      v = *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + (prow - 1)) * sw + (g.par2 ? 2 * px + par : px)) * g.c + c0);
       v = lrelu4(v * m4 + a4, slope);
     }
     csum += v;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void chsplit_kernel(const float* __restrict__ 
 }
 
 // db[cb*32 + ch] += sum over blocks of colpart[cb][blk][ch]; grid (cb, slices)
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, long nblk, int cvalid) {
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, long nblk, int cvalid, int cbh) {
   __shared__ float red[8][32];
   const int cb = blockIdx.x, j = threadIdx.x >> 5, ch = threadIdx.x & 31;
   float t = 0.f;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
     float u = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) u += red[k][threadIdx.x];
-    const int c = cb * 32 + threadIdx.x;
+    const int c = (cb % cbh) * 32 + threadIdx.x;         // (phase mode: both column phases of a channel block add into it)
     if (c < cvalid) atomicAdd(db + c, u);
   }
 }
@@ -145,10 +151,12 @@ struct GArgs {
 // rows a step reads only one is new.  Operands arrive by LDS-DMA DIST steps ahead of their use (a DMA round trip is ~3 us, a step
 // ~1.5-2 us): a ring of DIST+5 A-row slots and DIST+1 dY stages; every wave issues the SAME number of 1-KB pieces per step so the wait
 // before a step is a literal `s_waitcnt vmcnt(pieces of the later steps)` and never drains the prefetch.
-template <int BF, int KG> struct WgCfg {
+template <int BF, int KG, int S = 1> struct WgCfg {
   static constexpr int NPL = BF ? 1 : 2;
   static constexpr int DIST = BF ? 4 : 2;
-  static constexpr int RING = DIST + 5, STAGES = DIST + 1;
+  // rows alive while step t is computed: its own three + S new ones for each of the DIST requested steps + (3 - S) more when one of
+  // those starts a strip (it brings three rows)
+  static constexpr int RING = 3 + DIST * S + (3 - S), STAGES = DIST + 1;      // (S = 1: DIST + 5)
   static constexpr int XPL = (2 * KG + 2) * 512, XROW = NPL * XPL;   // one A row: [plane][seg 2KG+2][32 ch][16 B]
   static constexpr int YPL = 2 * KG * 512, YW = NPL * YPL;          // dY of one channel block: [plane][seg 2KG][32 ch][16 B]
   static constexpr int lds(int nwv) { return RING * XROW + STAGES * nwv * YW; }
@@ -174,14 +182,19 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 #define WT_ADD(var, t0v) do { } while (0)
 #endif
 
-template <int NWV, int BF, int KG>
+// S = 2, DXM: the stride-2 layers (DownBlock.downsampler AttResUNet.py:67, UpBlock.upsampler :80).  The A operand is a column-phase T
+// (chsplit par2) of the HIGH-resolution tensor, the dY operand a plain T of the low-resolution one; a step (low-res row oy) reads the
+// high-res rows 2oy-1, 2oy, 2oy+1 -- TWO new ring rows per step instead of one -- and DXM masks the column shifts that are computed
+// (bit dx: shift dx-1): a stride-2 window never needs the +1 shift (0b011), the 2x2 transposed conv only the aligned one (0b010).
+// Which (tap row, shift, column phase) is which weight tap is the reduction kernel's business (wgrad_reduce_s2_kernel).
+template <int NWV, int BF, int KG, int S = 1, int DXM = 7>
 __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_wgrad_f16_kernel(const GArgs a) {
-  using Cfg = WgCfg<BF, KG>;
+  using Cfg = WgCfg<BF, KG, S>;
   constexpr int NW = KG * NWV, NPL = Cfg::NPL, DIST = Cfg::DIST, RING = Cfg::RING, STAGES = Cfg::STAGES;
   constexpr int XPL = Cfg::XPL, XROW = Cfg::XROW, YPL = Cfg::YPL, YW = Cfg::YW, YST = NWV * YW;
   constexpr int XQ = KG + 1;                             // 1-KB pieces (two segments) of one plane of an A row
   constexpr int NYQ = NWV * NPL * KG;                    // dY pieces of a step
-  constexpr int NRQ = NPL * XQ + NYQ, NFQ = NPL * 3 * XQ + NYQ;   // pieces of a normal step / of the first step of a strip
+  constexpr int NRQ = NPL * S * XQ + NYQ, NFQ = NPL * 3 * XQ + NYQ;   // pieces of a normal step (S new rows) / of the first step of a strip
   constexpr int PN = (NRQ + NW - 1) / NW, PF = (NFQ + NW - 1) / NW;   // ... per wave (the round-up repeats a piece)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const xs = smem;                                 // RING row slots
@@ -232,24 +245,28 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
     const char* yrow = nullptr;
     auto seek = [&]() {
       const int img = istrip / a.nxs, xsi = istrip - img * a.nxs;
-      xrow = uniform_ptr(a.xt + ((size_t)img * (a.h + 2) + iy) * rowx + (size_t)cib * 2 * plx + (size_t)xsi * 2 * KG * 512);
+      xrow = uniform_ptr(a.xt + ((size_t)img * (S * a.h + 2) + S * iy) * rowx + (size_t)cib * 2 * plx + (size_t)xsi * 2 * KG * 512);
       yrow = uniform_ptr(a.yt + ((size_t)img * (a.h + 2) + iy + 1) * rowy + (size_t)(xsi * 2 * KG + 1) * 512);
     };
     seek();
     // The pieces this wave issues on a NORMAL step never change (piece q = i * NW + wv): decode them once.
     unsigned nsrc[PN], ndst[PN];                         // source offset from xrow + 2 rows / yrow; LDS offset inside the slot / stage
     bool nisx[PN];
+    [[maybe_unused]] bool nrr[PN];                       // S = 2: which of the two new rows
 #pragma unroll
     for (int i = 0; i < PN; ++i) {
       int q = i * NW + wv;
       if (q >= NRQ) q -= NYQ;                            // round-up: repeat a dY piece
-      nisx[i] = q < NPL * XQ;
+      nisx[i] = q < NPL * S * XQ;
+      nrr[i] = false;
       if (nisx[i]) {
-        const int plane = q / XQ, s2 = q - plane * XQ;
+        const int rr = q / (NPL * XQ), q1 = q - rr * (NPL * XQ);
+        const int plane = q1 / XQ, s2 = q1 - plane * XQ;
+        nrr[i] = rr != 0;
         nsrc[i] = (unsigned)(plane * plx + s2 * 1024);
         ndst[i] = plane * XPL + s2 * 1024;
       } else {
-        const int qy = q - NPL * XQ;
+        const int qy = q - NPL * S * XQ;
         const int w2 = qy / (NPL * KG), rem = qy - w2 * (NPL * KG), plane = rem / KG, s2 = rem - plane * KG;
         const int cb2 = min(cgrp * NWV + w2, a.ncob - 1);
         nsrc[i] = (unsigned)(((size_t)cb2 * 2 + plane) * plx + s2 * 1024);
@@ -263,16 +280,17 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
       const unsigned ystage = ((iu - t0) % STAGES) * YST;
       if (!first) {
         // the common case: one new A row (padded row iy + 2) + the step's dY; a handful of scalar instructions per piece
-        const char* const xnew = xrow + 2 * rowx;
-        const unsigned xslot = (icnt % RING) * XROW;
+        const char* const xnew = xrow + (3 - S) * rowx;        // (S = 2: padded rows 2iy+1 and 2iy+2; row 2iy came with the previous step)
+        const char* const xnew2 = xrow + 2 * rowx;
+        const unsigned xslot = (icnt % RING) * XROW, xslot2 = ((icnt + 1) % RING) * XROW;
 #pragma unroll
         for (int i = 0; i < PN; ++i) {
-          const char* const src = (nisx[i] ? xnew : yrow) + nsrc[i];
-          const unsigned dst = ndst[i] + (nisx[i] ? xslot : ystage);
+          const char* const src = (nisx[i] ? (S == 2 && nrr[i] ? xnew2 : xnew) : yrow) + nsrc[i];
+          const unsigned dst = ndst[i] + (nisx[i] ? (S == 2 && nrr[i] ? xslot2 : xslot) : ystage);
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane16),
                                            (__attribute__((address_space(3))) void*)(smem + dst), 16, 0, 0);
         }
-        icnt += 1;
+        icnt += S;
       } else {
         char* const ydst = ys + ystage;
 #pragma unroll
@@ -295,7 +313,7 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
         icnt += 3;
       }
       ++iu; ++iy;
-      xrow += rowx; yrow += rowy;
+      xrow += S * rowx; yrow += rowy;
       if (iy == a.h) { iy = 0; ++istrip; if (iu < t1) seek(); }
       return first;
     };
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
           const u32x4 d = cur.d;
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
+            if (!((DXM >> dx) & 1)) continue;
             u32x4 f = d;
             if (dx == 0)
               f = u32x4{__builtin_amdgcn_alignbyte(d.x, cur.dm, 2), __builtin_amdgcn_alignbyte(d.y, d.x, 2), __builtin_amdgcn_alignbyte(d.z, d.y, 2),
@@ -384,8 +403,8 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
         }
       }
       WT_ADD(tc, tmark);
-      ++ccnt; ++cy;
-      if (cy == a.h) { cy = 0; ccnt += 2; }              // the next step starts a strip: its request brought three new rows, not one
+      ccnt += S; ++cy;
+      if (cy == a.h) { cy = 0; ccnt += 3 - S; }          // the next step starts a strip: its request brought three new rows, not S
     }
   }
 
@@ -465,10 +484,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[((size_t)co * cin + ci) * 9 + t] = s[0];
 }
 
+// The stride-2 forms (conv_wgrad_f16_kernel<.., S = 2, DXM>): part[run][t' = tap row * 3 + shift][m][n''], n'' = column phase * hp + channel.
+//   mode 0, 3x3 stride-2 conv, dw[co][ci][ky][kx]: input column 2ox + kx - 1 is the even phase at ox (kx = 1: aligned), the odd phase at
+//           ox - 1 (kx = 0: shift -1) or at ox (kx = 2: aligned); tap row ky as in the stride-1 kernel (row 2oy + ky - 1)
+//   mode 1, 2x2 transposed conv, dw[ci][co][a][b] = sum_p x[p][ci] dy[2p + (a, b)][co]: row 2p + a is tap row a + 1, column phase b, aligned
+// Runs are added in order: bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_s2_kernel(const float* __restrict__ part, float* __restrict__ dw, int nrun, int mp, int np, int hp,
+                                                              int mreal, int nreal, int mode) {
+  const int ntap = mode ? 4 : 9;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= mreal * nreal * ntap) return;
+  const int tt = i % ntap, n = (i / ntap) % nreal, m = i / (ntap * nreal);
+  int tp, par;
+  if (mode == 0) {
+    const int ky = tt / 3, kx = tt - 3 * ky;
+    par = kx != 1;
+    tp = ky * 3 + (kx == 0 ? 0 : 1);
+  } else {
+    par = tt & 1;
+    tp = ((tt >> 1) + 1) * 3 + 1;
+  }
+  const size_t per = (size_t)9 * mp * np;
+  const float* q = part + ((size_t)tp * mp + m) * np + (size_t)par * hp + n;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  int r = 0;
+  for (; r + 4 <= nrun; r += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s4[k] += q[(size_t)(r + k) * per];
+  }
+  for (int k = 0; r + k < nrun; ++k) s4[k] += q[(size_t)(r + k) * per];
+  dw[i] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
 // k-steps (waves) per channel block: 64-pixel steps = twelve-wave workgroups, one per CU; images of at most 32 columns would waste
 // half of every such step, they take 32-pixel steps = six-wave workgroups, two per CU (2/3/3/4 waves on the SIMDs, still the better deal).
 struct Plan { int kg, nwv, pairs, split, run, nxs, nsteps; };
-inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
+inline Plan make_plan(int n, int h, int w, int ncob, int ncib, int s = 1) {
   Plan p;
   static const int kg_env = getenv("VIRNET_WGRAD_KG") ? atoi(getenv("VIRNET_WGRAD_KG")) : 0;   // tuning override: 2 or 4
   p.kg = w <= 32 ? 2 : (kg_env == 2 || kg_env == 4 ? kg_env : 4);   // (T rows of narrow images only have room for 32-pixel steps)
@@ -477,7 +528,7 @@ inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
   p.nsteps = n * p.nxs * h;
   const int groups = (ncob + p.nwv - 1) / p.nwv;
   p.pairs = groups * ncib;
-  int split = (p.kg == 2 ? 512 : 256) / p.pairs;         // workgroups per CU: the LDS rings take 142 KB (64-pixel steps) / 78 KB (32)
+  int split = (p.kg == 2 && s == 1 ? 512 : 256) / p.pairs;   // workgroups per CU: the LDS rings take 142 KB (64-pixel steps) / 78 KB (32; stride-2 form: 84 KB)
   if (split > p.nsteps / 4) split = p.nsteps / 4;        // runs of at least four steps (each run primes three rows)
   if (split < 1) split = 1;
   p.run = (p.nsteps + split - 1) / split;
@@ -485,11 +536,12 @@ inline Plan make_plan(int n, int h, int w, int ncob, int ncib) {
   return p;
 }
 
-template <int NWV, int BF, int KG>
+template <int NWV, int BF, int KG, int S = 1, int DXM = 7>
 int launch_g(GArgs k, const Plan& p, hipStream_t st) {
-  constexpr int LDS = WgCfg<BF, KG>::lds(NWV) > 3 * 16 * 64 * 4 * NWV ? WgCfg<BF, KG>::lds(NWV) : 3 * 16 * 64 * 4 * NWV;   // K loop / epilogue exchange
+  constexpr int LDS = WgCfg<BF, KG, S>::lds(NWV) > 3 * 16 * 64 * 4 * NWV ? WgCfg<BF, KG, S>::lds(NWV) : 3 * 16 * 64 * 4 * NWV;   // K loop / epilogue exchange
+  static_assert(LDS <= 160 * 1024, "conv_wgrad_f16: LDS over 160 KB");
   static unsigned long long attr_done = 0;
-  auto kern = conv_wgrad_f16_kernel<NWV, BF, KG>;
+  auto kern = conv_wgrad_f16_kernel<NWV, BF, KG, S, DXM>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wgrad_f16): %s", hipGetErrorString(e));
@@ -499,9 +551,9 @@ int launch_g(GArgs k, const Plan& p, hipStream_t st) {
   return virnet::check_launch("conv_wgrad_f16 launch");
 }
 
-template <int BF, int KG>
+template <int BF, int KG, int S = 1, int DXM = 7>
 int launch_nwv(const GArgs& k, const Plan& p, hipStream_t st) {
-  return p.nwv == 3 ? launch_g<3, BF, KG>(k, p, st) : p.nwv == 2 ? launch_g<2, BF, KG>(k, p, st) : launch_g<1, BF, KG>(k, p, st);
+  return p.nwv == 3 ? launch_g<3, BF, KG, S, DXM>(k, p, st) : p.nwv == 2 ? launch_g<2, BF, KG, S, DXM>(k, p, st) : launch_g<1, BF, KG, S, DXM>(k, p, st);
 }
 
 static long long* g_wlog = nullptr;
@@ -519,14 +571,24 @@ extern "C" size_t virnet_chsplit_colsum_bytes(int n, int h, int w, int c) {
   return (size_t)n * (h + 2) * ((t_nseg(w) + 7) / 8) * ((c + 31) / 32) * 32 * sizeof(float);
 }
 
-extern "C" int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
-                              int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream) {
+extern "C" size_t virnet_chsplit_s2_bytes(int n, int h, int w, int c) {
+  return (size_t)n * (h + 2) * 2 * ((c + 31) / 32) * 2 * t_nseg(w / 2) * 512;
+}
+
+extern "C" size_t virnet_chsplit_s2_colsum_bytes(int n, int h, int w, int c) {
+  return (size_t)n * (h + 2) * ((t_nseg(w / 2) + 7) / 8) * 2 * ((c + 31) / 32) * 32 * sizeof(float);
+}
+
+static int chsplit_launch(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                          int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream, int par2) {
   VIRNET_REQUIRE(x && out, "virnet_chsplit: NULL pointer");
   VIRNET_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "virnet_chsplit: bad shape n=%d h=%d w=%d c=%d (c %% 4 == 0)", n, h, w, c);
+  VIRNET_REQUIRE(!par2 || (w % 2 == 0 && c % 32 == 0), "virnet_chsplit_s2: w=%d must be even and c=%d a multiple of 32", w, c);
   VIRNET_REQUIRE((in_mul == nullptr) == (in_add == nullptr), "virnet_chsplit: in_mul and in_add go together");
   VIRNET_REQUIRE(!in_act || (in_slope >= 0.f && in_slope <= 1.f), "virnet_chsplit: in_slope=%g outside [0,1]", in_slope);
   VIRNET_REQUIRE(!db || (col_scratch && cvalid >= 1 && cvalid <= c), "virnet_chsplit: db needs col_scratch and 1 <= cvalid=%d <= c=%d", cvalid, c);
-  TGeom g{n, h, w, c, (c + 31) / 32, t_nseg(w)};
+  if (par2) w /= 2;                                       // geometry of T: one row per source row, half the columns, twice the blocks
+  TGeom g{n, h, w, c, (par2 ? 2 : 1) * ((c + 31) / 32), t_nseg(w), par2};
   const int sgs = (g.nseg + 7) / 8;
   const long blocks = (long)n * (h + 2) * g.cb * sgs;
   VIRNET_REQUIRE(blocks < (1L << 31), "virnet_chsplit: tensor too large");
@@ -540,10 +602,20 @@ extern "C" int virnet_chsplit(const float* x, int n, int h, int w, int c, int in
   if (db) {
     const long nblk = (long)n * (h + 2) * sgs;
     const int slices = (int)(nblk / 64 < 1 ? 1 : nblk / 64 > 64 ? 64 : nblk / 64);
-    hipLaunchKernelGGL(colpart_reduce_kernel, dim3(g.cb, slices), dim3(256), 0, st, col_scratch, db, nblk, cvalid);
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3(g.cb, slices), dim3(256), 0, st, col_scratch, db, nblk, cvalid, par2 ? g.cb / 2 : g.cb);
     return virnet::check_launch("colpart_reduce launch");
   }
   return 0;
+}
+
+extern "C" int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                              int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream) {
+  return chsplit_launch(x, n, h, w, c, in_act, in_slope, in_mul, in_add, bf16, out, col_scratch, db, cvalid, stream, 0);
+}
+
+extern "C" int virnet_chsplit_s2(const float* x, int n, int h, int w, int c, int in_act, float in_slope, const float* in_mul, const float* in_add,
+                                 int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream) {
+  return chsplit_launch(x, n, h, w, c, in_act, in_slope, in_mul, in_add, bf16, out, col_scratch, db, cvalid, stream, 1);
 }
 
 extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
@@ -572,5 +644,43 @@ extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, 
 extern "C" size_t virnet_conv_wgrad_f16_scratch_bytes(int n, int h, int w, int cx, int cy) {
   const int ncib = (cx + 31) / 32, ncob = (cy + 31) / 32;
   const Plan p = make_plan(n, h, w, ncob, ncib);
+  return (size_t)p.split * 9 * ncob * 32 * ncib * 32 * sizeof(float);
+}
+
+extern "C" int virnet_conv_wgrad_f16_s2(const void* hi_t, const void* lo_t, float* dw, float* scratch, int n, int oh, int ow, int chi, int clo,
+                                        int cin, int cout, int mode, int bf16, void* stream) {
+  VIRNET_REQUIRE(hi_t && lo_t && dw && scratch, "virnet_conv_wgrad_f16_s2: NULL pointer");
+  VIRNET_REQUIRE(mode == 0 || mode == 1, "virnet_conv_wgrad_f16_s2: mode=%d (0: 3x3 stride-2 conv, 1: 2x2 transposed conv)", mode);
+  VIRNET_REQUIRE(n > 0 && oh > 4 && ow > 0, "virnet_conv_wgrad_f16_s2: oh=%d (the row ring needs oh >= 5) or empty input", oh);
+  VIRNET_REQUIRE(chi % 32 == 0, "virnet_conv_wgrad_f16_s2: the high-resolution tensor stores %d channels (multiple of 32 needed)", chi);
+  const int mreal = mode ? cin : cout, nreal = mode ? cout : cin;     // rows come from the low-res tensor, columns from the high-res one
+  VIRNET_REQUIRE(mreal >= 1 && mreal <= clo && nreal >= 1 && nreal <= chi, "virnet_conv_wgrad_f16_s2: cin=%d / cout=%d beyond the stored channels (%d low-res, %d high-res)",
+                 cin, cout, clo, chi);
+  GArgs k{};
+  k.xt = static_cast<const char*>(hi_t); k.yt = static_cast<const char*>(lo_t); k.dw = scratch;
+  k.n = n; k.h = oh; k.w = ow; k.nseg = t_nseg(ow);
+  k.cin = nreal; k.cout = mreal;
+  k.tlog = nullptr;
+  k.ncib = 2 * (chi / 32); k.ncob = (clo + 31) / 32;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const Plan p = make_plan(n, oh, ow, k.ncob, k.ncib, 2);
+  int rc;
+  if (mode == 0) {
+    if (p.kg == 2) rc = bf16 ? launch_nwv<1, 2, 2, 3>(k, p, st) : launch_nwv<0, 2, 2, 3>(k, p, st);
+    else rc = bf16 ? launch_nwv<1, 4, 2, 3>(k, p, st) : launch_nwv<0, 4, 2, 3>(k, p, st);
+  } else {
+    if (p.kg == 2) rc = bf16 ? launch_nwv<1, 2, 2, 2>(k, p, st) : launch_nwv<0, 2, 2, 2>(k, p, st);
+    else rc = bf16 ? launch_nwv<1, 4, 2, 2>(k, p, st) : launch_nwv<0, 4, 2, 2>(k, p, st);
+  }
+  if (rc) return rc;
+  const int mp = k.ncob * 32, np = k.ncib * 32;
+  const int total = mreal * nreal * (mode ? 4 : 9);
+  hipLaunchKernelGGL(wgrad_reduce_s2_kernel, dim3((total + 255) / 256), dim3(256), 0, st, scratch, dw, p.split, mp, np, np / 2, mreal, nreal, mode);
+  return virnet::check_launch("wgrad_reduce_s2 launch");
+}
+
+extern "C" size_t virnet_conv_wgrad_f16_s2_scratch_bytes(int n, int oh, int ow, int chi, int clo) {
+  const int ncib = 2 * (chi / 32), ncob = (clo + 31) / 32;
+  const Plan p = make_plan(n, oh, ow, ncob, ncib, 2);
   return (size_t)p.split * 9 * ncob * 32 * ncib * 32 * sizeof(float);
 }

@@ -34,6 +34,7 @@ class PackedWeight:
     bf16: Optional[Tensor] = None   # bf16-operand image (virnet_pack_bf16_weight) of a C->C stride-1 3x3 layer (form "bf16" only)
     wx4: Optional[Tensor] = None    # Winograd F(4,3)-along-x split-fp16 image (virnet_pack_wx4_weight) of a C->C stride-1 3x3 layer (form "wx4")
     exit: Optional[Tensor] = None   # taps-as-rows split-fp16 image (virnet_pack_exit_weight) of a 3x3 layer with <= 3 output channels
+    s2: Optional["PackedWeight"] = None   # dgrad packing of the 2x2 transposed conv: the same GEMM as a 3x3 stride-2 conv (convt_dgrad)
 
 
 class LaunchTimer:
@@ -315,6 +316,14 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
         nat.check(lib.virnet_pack_weight(nat.ptr(weight), kind, cout, cin, ks, plan.cin_pad, plan.n_pad, plan.nrep, nat.ptr(out),
                                          nat.stream_handle()), "pack_weight(dgrad)")
         pw = PackedWeight(out, None, gemm_ks, cin, (4 * cout if transposed else cout), plan.cin_pad, plan.n_pad, plan.nrep, False)
+        if transposed and _f16_family() and cin % 32 == 0 and cout % 16 == 0:
+            # dx[p][ci] = sum_{a,b,co} dy[2p+(a,b)][co] W[ci][co][a][b] is a 3x3 stride-2 pad-1 conv of dy whose taps (a+1, b+1) hold W and
+            # whose first row / column are zero: it runs on csrc/conv_f16_s2.hip (split-fp16) straight from the high-res gradient
+            k3 = torch.zeros((cin, cout, 3, 3), dtype=torch.float32, device=weight.device)
+            k3[:, :, 1:, 1:] = weight
+            pw.s2 = pack_weight(k3, None, stride=2)
+        if not transposed and cin % 32 == 0 and cout < WINO_MIN_CHANNELS and _f16_family():
+            pw.f16 = pack_f16_weight(weight, dgrad=True)         # few-channel gradient -> features (tail / conv_last backward): one 16-channel chunk
         if not transposed and cin % 32 == 0 and cout >= WINO_MIN_CHANNELS:
             if conv_form() == "wino":
                 pw.wino = pack_wino_weight(weight, dgrad=True)
@@ -721,6 +730,9 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
         return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
                                bias_channels=bias_channels)
+    if not transposed and stride == 2 and ks == 3 and _wgrad_s2_ok(h // 2, cx):
+        return _conv_wgrad_f16_s2(x, dy, weight_shape, 0, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
+                                  bias_channels=bias_channels)
     dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     rows = 4 * cout if transposed else cout
     ctr = torch.zeros(((rows + 31) // 32) * ((cin + 31) // 32), dtype=torch.int32, device=x.device)
@@ -740,6 +752,36 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     if bias_channels is not None:
         return dw, colsum(dy, bias_channels)
     return dw
+
+
+def convt_dgrad(dy: Tensor, pw: PackedWeight) -> Tensor:
+    """Input gradient [n,h,w,cin] of ConvTranspose2d(k=2, s=2) from the NHWC gradient of its output [n,2h,2w,cout] and the layer's
+    dgrad packing: on the split-fp16 stride-2 kernel when the packing carries that form, else the fp32 pointwise GEMM over the
+    space-to-depth gradient."""
+    if pw.s2 is not None and pw.s2.f16 is not None and _f16_family():
+        return conv_mfma(dy, pw.s2, stride=2, want_raw=True)[0]
+    return conv_mfma(space_to_depth2(dy), pw, want_raw=True)[0]
+
+
+def _wgrad_s2_ok(oh: int, chi: int) -> bool:
+    """The stride-2 layers' weight gradients on the f16 pipe (csrc/wgrad_f16.hip, S = 2): split-fp16 family, a row ring of >= 5
+    low-res rows, whole 32-channel blocks in the high-resolution operand."""
+    return (conv_form() in ("f16x3", "bf16", "wx4") and _env("VIRNET_WGRAD_FORM", "f16") != "f32" and oh >= 5 and chi % 32 == 0)
+
+
+def convt_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...]):
+    """(dw [cin][cout][2][2], db [cout]) of ConvTranspose2d(k=2, s=2) (UpBlock.upsampler, AttResUNet.py:80) from its NHWC input ``x``
+    [n,h,w,cx] and the NHWC gradient of its output ``dy`` [n,2h,2w,cout]: on the f16 pipe (the bias gradient rides on the re-layout pass
+    over ``dy``), or -- fp32 forms, tiny maps -- the fp32 kernel on the space-to-depth gradient plus a column sum."""
+    _dev_check(x, "x"); _dev_check(dy, "dy")
+    n, h, w, cx = x.shape
+    cin, cout = weight_shape[0], weight_shape[1]
+    if tuple(dy.shape) != (n, 2 * h, 2 * w, cout):
+        raise ValueError(f"dy shape {tuple(dy.shape)} != {(n, 2 * h, 2 * w, cout)}")
+    if _wgrad_s2_ok(h, cout):
+        return _conv_wgrad_f16_s2(dy, x, weight_shape, 1, None, None, None, bf16=(conv_form() == "bf16" and min(cin, cout) >= 32),
+                                  bias_channels=cout)
+    return conv_wgrad(x, space_to_depth2(dy), weight_shape, transposed=True), colsum(dy)
 
 
 _WORKSPACES: dict = {}
@@ -784,6 +826,52 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
     if timed:
         e1.record()
         _TIMER.records.append((("wgrad_f16", 3, 1, 0), 2.0 * n * h * w * cin * cout * 9, e0, e1))
+    return dw if bias_channels is None else (dw, db)
+
+
+def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope, in_mul, in_add, *, bf16: bool,
+                       bias_channels: Optional[int] = None):
+    """Weight gradient of a stride-2 layer on the f16 pipe.  ``hi`` = the high-resolution operand [n,2oh,2ow,chi], re-laid as a
+    column-phase T (``virnet_chsplit_s2``); ``lo`` = the low-resolution one [n,oh,ow,clo] (plain T).  mode 0: 3x3 stride-2 conv (hi = its
+    input, with the staging transform; lo = dY, whose pass yields the bias gradient); mode 1: 2x2 transposed conv (hi = dY: bias
+    gradient from ITS pass; lo = the input)."""
+    lib = nat.load()
+    n, hh, hw, chi = hi.shape
+    _, oh, ow, clo = lo.shape
+    if (hh, hw) != (2 * oh, 2 * ow):
+        raise ValueError(f"stride-2 weight gradient: {tuple(hi.shape)} is not twice {tuple(lo.shape)}")
+    st = nat.stream_handle()
+    ht = _workspace("wgrad_xt", lib.virnet_chsplit_s2_bytes(n, hh, hw, chi), hi.device)
+    lt = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, oh, ow, clo), hi.device)
+    timed = _TIMER is not None
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    db = None
+    hcol = lcol = None
+    if bias_channels is not None:
+        db = torch.zeros(bias_channels, dtype=torch.float32, device=hi.device)
+        if mode == 1:
+            hcol = _workspace("wgrad_col", lib.virnet_chsplit_s2_colsum_bytes(n, hh, hw, chi), hi.device)
+        else:
+            lcol = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, oh, ow, clo), hi.device)
+    bc = 0 if bias_channels is None else bias_channels
+    nat.check(lib.virnet_chsplit_s2(nat.ptr(hi), n, hh, hw, chi, int(in_slope is not None), 0.0 if in_slope is None else in_slope,
+                                    nat.ptr(in_mul), nat.ptr(in_add), int(bf16), nat.ptr(ht), nat.ptr(hcol), nat.ptr(db) if hcol is not None else None,
+                                    bc if hcol is not None else 0, st), "chsplit_s2")
+    nat.check(lib.virnet_chsplit(nat.ptr(lo), n, oh, ow, clo, 0, 0.0, None, None, int(bf16), nat.ptr(lt), nat.ptr(lcol),
+                                 nat.ptr(db) if lcol is not None else None, bc if lcol is not None else 0, st), "chsplit")
+    if mode == 0:
+        cout, cin = weight_shape[0], weight_shape[1]
+    else:
+        cin, cout = weight_shape[0], weight_shape[1]
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=hi.device)          # every element is written by the reduction
+    scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_s2_scratch_bytes(n, oh, ow, chi, clo), hi.device)
+    nat.check(lib.virnet_conv_wgrad_f16_s2(nat.ptr(ht), nat.ptr(lt), nat.ptr(dw), nat.ptr(scr), n, oh, ow, chi, clo, cin, cout, mode, int(bf16), st),
+              "conv_wgrad_f16_s2")
+    if timed:
+        e1.record()
+        _TIMER.records.append((("wgrad_f16_s2", 3 if mode == 0 else 2, 2, mode), 2.0 * n * oh * ow * cin * cout * (4 if mode else 9), e0, e1))
     return dw if bias_channels is None else (dw, db)
 
 

@@ -168,22 +168,22 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
                 dx, _ = ops.conv_mfma(d_f1, mod.conv1.packed_dgrad(), mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
             elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
                 dbridge[aux] = dx
-                s2d = ops.space_to_depth2(dx)
                 side = _side_stream(dx.device)
                 main = torch.cuda.current_stream(dx.device)
                 if side is not None:
                     side.wait_stream(main)
                 with torch.cuda.stream(side if side is not None else main):        # same stream as every other push (bucket order)
-                    new = {mod.weight: ops.conv_wgrad(x_in, s2d, tuple(mod.weight.shape), transposed=True), mod.bias: ops.colsum(dx)}
+                    dw, db = ops.convt_wgrad(x_in, dx, tuple(mod.weight.shape))
+                    new = {mod.weight: dw, mod.bias: db}
                     if reducer is not None:
                         reducer.push(new)
                 if side is not None:
-                    for t in (x_in, s2d, dx):
+                    for t in (x_in, dx):
                         t.record_stream(side)
                     for g in new.values():
                         g.record_stream(main)
                 grads.update(new)
-                dx, _ = ops.conv_mfma(s2d, mod.packed_dgrad(), want_raw=True)
+                dx = ops.convt_dgrad(dx, mod.packed_dgrad())
             else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
                 _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer)
                 nb -= 1

@@ -79,10 +79,9 @@ class _ConvT2x2(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         dy = dy.contiguous()
-        s2d = ops.space_to_depth2(dy)
-        dx = ops.conv_mfma(s2d, conv.packed_dgrad(), want_raw=True)[0] if ctx.needs_input_grad[0] else None
-        dw = ops.conv_wgrad(x, s2d, tuple(conv.weight.shape), transposed=True)
-        return dx, dw, ops.colsum(dy), None
+        dx = ops.convt_dgrad(dy, conv.packed_dgrad()) if ctx.needs_input_grad[0] else None
+        dw, db = ops.convt_wgrad(x, dy, tuple(conv.weight.shape))
+        return dx, dw, db, None
 
 
 class _ConvExit(torch.autograd.Function):
