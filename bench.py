@@ -431,6 +431,8 @@ def main():
                 return "conv_wgrad<ks=%d,s=%d,t=%d>" % k[1:]
             if k[0] == "wgrad_f16":
                 return "chsplit x2 + conv_wgrad_f16 + reduce <ks=%d,s=%d,t=%d>" % k[1:]
+            if k[0] == "wgrad_f16_s2":
+                return "chsplit_s2 + chsplit + conv_wgrad_f16<S=2> + reduce <ks=%d,s=%d,t=%d>" % k[1:]
             if k[0] == "exit":
                 return "conv_exit<cout=%d>" % k[1]
             if k[0] in ("wino", "f16x3", "f16x3_s2", "f16x3_t", "bf16", "wx4"):
