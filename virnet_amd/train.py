@@ -11,7 +11,8 @@ whose backward walks the layers in reverse with hand-written kernels only:
   * bias gradients   : ``virnet_colsum``.
 
 The ELBO itself (loss/ELBO_simple.py) stays host-side PyTorch on ``mu`` and ``sigma`` as BASELINE.json's north_star asks; autograd
-hands its gradients to ``backward`` below.  fp32 throughout.  SISR training (KNet / SFT backward) is not built yet.
+hands its gradients to ``backward`` below.  The SISR step and the denoiser configurations with SFT conditioning (extra_mode Down / Both)
+run through per-layer nodes instead: virnet_amd/train_sisr.py.
 """
 from __future__ import annotations
 
@@ -44,9 +45,9 @@ def _thin(conv, x, crop, **kw):
 def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
     snet, rnet = net.SNet, net.RNet
     if snet.noise_avg:
-        raise NotImplementedError("training path: noise_avg=True (pooled variance) is not built")
+        raise NotImplementedError("fused denoiser step: noise_avg=True runs through train_sisr.denoise_forward_nodes (denoise_forward_autograd routes it)")
     if rnet.extra_mode not in ("input", "null"):
-        raise NotImplementedError("training path: SFT conditioning (extra_mode down/both) is not built yet")
+        raise NotImplementedError("fused denoiser step: extra_mode Down / Both runs through train_sisr.denoise_forward_nodes (denoise_forward_autograd routes it)")
     x = _prep(x, snet.in_channels)
     n, _, h, w = x.shape
     tape = _Tape()
@@ -266,5 +267,11 @@ class DenoiseFunction(torch.autograd.Function):
 
 
 def denoise_forward_autograd(net, x: Tensor) -> Tuple[Tensor, Tensor]:
+    if net.SNet.noise_avg or net.RNet.extra_mode not in ("input", "null"):
+        # SFT conditioning from the per-pixel variance map (extra_mode Down / Both) or a pooled variance: the per-layer autograd nodes
+        # of the SISR step cover these (train_sisr.denoise_forward_nodes); the fused single-Function step below is the shipped
+        # configurations' path (configs/denoising_*.json: extra_mode Input, noise_avg False)
+        from . import train_sisr
+        return train_sisr.denoise_forward_nodes(net, x)
     params = tuple(net.parameters())
     return DenoiseFunction.apply(x, net, *params)

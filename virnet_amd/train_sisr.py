@@ -11,7 +11,11 @@ host-side tensor plumbing in BASELINE.json's sense.
 So the numbers match the inference forward to fp32 noise, the step is complete (every one of the 225 parameters receives its gradient),
 and torch's DistributedDataParallel hooks fire layer by layer as the backward proceeds.
 
-Not built: per-pixel conditioning in training (``noise_avg=False``: SFT from maps, the JPEG variant of train_SISR.py:87).
+Per-pixel conditioning (``noise_avg=False``: the variance MAP feeds the head and the SFT layers, VIRNet.py:94, the JPEG variant of
+train_SISR.py:87; and the denoiser with ``extra_mode`` Down / Both) takes the unfused spelling of a residual block: the AttLayer runs as
+``F.linear`` over the NHWC conditioning map, the modulation ``lrelu(x*mul+add)`` as device elementwise ops under autograd, the 3x3
+convolutions on the same HIP nodes -- a rare configuration (no shipped config uses it), complete rather than fast.
+``denoise_forward_nodes`` runs the DENOISER through the same nodes for the configurations its fused step (train.py) does not cover.
 """
 from __future__ import annotations
 
@@ -234,8 +238,14 @@ def _att_layer(vec: Tensor, att) -> Tuple[Tensor, Tensor]:
 
 
 def _res_block(x: Tensor, blk, vec: Optional[Tensor]) -> Tensor:
-    """AttResBlock.forward (AttResUNet.py:48-60) on NHWC tensors: one fused node (the AttLayer MLPs stay autograd on [N, C] vectors)."""
+    """AttResBlock.forward (AttResUNet.py:48-60) on NHWC tensors: one fused node (the AttLayer MLPs stay autograd on [N, C] vectors).
+    ``vec`` [N, e]: spatially constant conditioning; [N, h, w, e]: a per-pixel conditioning map -> the unfused spelling."""
     c1, c2 = blk.conv1, blk.conv2
+    if vec is not None and blk.extra_chn > 0 and vec.dim() == 4:
+        mul1, add1 = _att_layer(vec, blk.sft1)                                  # [N, h, w, nf]: 1x1 convs = F.linear over the channel axis
+        f1 = _conv(F.leaky_relu(x * mul1 + add1, 0.2), c1)                      # AttResUNet.py:54-55
+        mul2, add2 = _att_layer(vec, blk.sft2)
+        return x + _conv(F.leaky_relu(f1 * mul2 + add2, 0.2), c2)               # AttResUNet.py:57-59
     if vec is not None and blk.extra_chn > 0:
         mul1, add1 = _att_layer(vec, blk.sft1)
         mul2, add2 = _att_layer(vec, blk.sft2)
@@ -246,7 +256,7 @@ def _res_block(x: Tensor, blk, vec: Optional[Tensor]) -> Tensor:
 # ----------------------------------------------------------------------------------------------------------------------
 # sub-networks
 # ----------------------------------------------------------------------------------------------------------------------
-def _snet(snet, x: Tensor) -> Tensor:
+def _snet(snet, x: Tensor, rescale=None) -> Tensor:
     """DnCNN.forward (DnCNN.py:37-44) -> raw log-variance, [N,C,h,w] or pooled [N,C,1,1]."""
     n, _, h, w = x.shape
     cur = _conv(ops.pack_input(x, h, w), snet.conv1)                # pre-activations; each following conv applies the LReLU on its input
@@ -254,10 +264,12 @@ def _snet(snet, x: Tensor) -> Tensor:
         cur = _act_conv(cur, snet.mid_layer[key], 0.25)
     last = snet.conv_last
     v = _ConvExit.apply(F.leaky_relu(cur, 0.25), last.weight, last.bias, last, (h, w))
+    if rescale is not None:
+        v = rescale(v)                                              # (in front of the mean: its backward divides by h*w)
     return v.mean(dim=(2, 3), keepdim=True) if snet.noise_avg else v
 
 
-def _knet(knet, x: Tensor) -> Tensor:
+def _knet(knet, x: Tensor, rescale=None) -> Tensor:
     """KernelNet.forward (KNet.py:52-59) -> [N, 3] = (lam1, lam2, rho)."""
     k = _HeadS4.apply(x, knet.head.weight)
     for rb in knet.body:
@@ -268,26 +280,46 @@ def _knet(knet, x: Tensor) -> Tensor:
         k = hcv * gate[:, None, None, :] + k                                    # KNet.py:26,38
     oh, ow = k.shape[1:3]
     tail = knet.tail["0"]
-    m = _ConvExit.apply(k, tail.weight, tail.bias, tail, (oh, ow)).mean(dim=(2, 3))          # KNet.py:49-50
+    m = _ConvExit.apply(k, tail.weight, tail.bias, tail, (oh, ow))
+    if rescale is not None:
+        m = rescale(m)
+    m = m.mean(dim=(2, 3))                                                      # KNet.py:49-50
     lam12 = torch.exp(torch.clamp(m[:, :-1], min=K_LOG_MIN, max=LOG_MAX))       # KNet.py:56
     return torch.cat((lam12, torch.tanh(m[:, -1:])), dim=1)                     # KNet.py:57-58
 
 
-def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int) -> Tensor:
-    """AttResUNet.forward (AttResUNet.py:141-175) on the nearest-upsampled image with per-image conditioning vectors."""
-    n, _, h0, w0 = x_in.shape
+def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int, emap: Optional[Tensor] = None) -> Tensor:
+    """AttResUNet.forward (AttResUNet.py:141-175) on the nearest-upsampled image with per-image conditioning vectors ``vec`` [N, ev]
+    and / or a per-pixel conditioning map ``emap`` [N, em, H, W] at the up-sampled resolution (channel order: vector, then map --
+    VIRNet.py:90-95)."""
+    n, c0, h0, w0 = x_in.shape
     H, W = h0 * sf, w0 * sf
     m = 1 << (rnet.depth - 1)
     hp, wp = _ceil_to(H, m), _ceil_to(W, m)
     mode = rnet.extra_mode
     feed_head, feed_down = mode in ("input", "both"), mode in ("down", "both")
-    if mode != "null" and (vec is None or vec.shape[1] != rnet.extra_chn):
-        raise ValueError(f"conditioning has {0 if vec is None else vec.shape[1]} channels, the network was built for {rnet.extra_chn}")
-    rec = _PackRecords.apply(x_in, vec, hp, wp, sf) if feed_head else ops.pack_input(x_in, hp, wp, sf=sf)
+    ne = (0 if vec is None else vec.shape[1]) + (0 if emap is None else emap.shape[1])
+    if mode != "null" and ne != rnet.extra_chn:
+        raise ValueError(f"conditioning has {ne} channels, the network was built for {rnet.extra_chn}")
+    emaps = None                                                                # padded NCHW extra maps (AttResUNet.py:150)
+    if emap is not None and mode != "null":
+        if tuple(emap.shape[-2:]) != (H, W):
+            raise ValueError(f"conditioning map is {tuple(emap.shape[-2:])}, the up-sampled image {(H, W)}")
+        parts = ([vec[:, :, None, None].expand(n, vec.shape[1], H, W)] if vec is not None else []) + [emap]
+        emaps = F.pad(torch.cat(parts, 1), (0, wp - W, 0, hp - H), mode="reflect") if (hp, wp) != (H, W) else torch.cat(parts, 1)
+    if not feed_head:
+        rec = ops.pack_input(x_in, hp, wp, sf=sf)
+    elif emaps is None:
+        rec = _PackRecords.apply(x_in, vec, hp, wp, sf)
+    else:                                                                       # records [image | extra maps | 0], the maps differentiable
+        img = ops.pack_input(x_in, hp, wp, sf=sf)
+        rec = torch.cat([img[..., :c0], emaps.permute(0, 2, 3, 1), img[..., c0 + ne:]], dim=-1)
     x = _conv(rec, rnet.head)                                                   # AttResUNet.py:153-155
-    cond = vec if feed_down else None
     bridges: List[Tensor] = []
     for ii, lvl in enumerate(rnet.down_path):
+        cond = None
+        if feed_down:                                                           # AttResUNet.py:158,168: nearest-resized extra maps per level
+            cond = vec if emaps is None else (emaps if ii == 0 else F.interpolate(emaps, x.shape[1:3], mode="nearest")).permute(0, 2, 3, 1)
         for blk in lvl.body:
             x = _res_block(x, blk, cond)
         if ii + 1 < len(rnet.down_path):
@@ -308,34 +340,39 @@ def _rnet(rnet, x_in: Tensor, vec: Optional[Tensor], sf: int) -> Tensor:
 # loss-scale independence of the backward.  Every GEMM of the backward splits its operands into fp16 pairs, exact between 6e-5 and
 # 65504; a mean-reduced loss hands over ~1e-7 per entry, a sum-reduced one or a GradScaler 1e4 and more.  The backward is linear, so the
 # three incoming gradients are multiplied by ONE power of two at the network's boundary (this node sees them together) and every
-# parameter gradient is divided by it again where it leaves the graph (a hook on the leaf).  The factor is 1 -- and the hooks do
-# nothing -- while the largest incoming entry lies in [2^-10, 2^10]; deciding that costs one device -> host read per backward.
+# parameter gradient is divided by it again where it leaves the graph (a _Gate node at the parameters' entry).  The factor is 1 while the
+# largest incoming entry lies in [2^-10, 2^10]; it is computed and applied on the device (no host read).  Encoders whose output passes a
+# spatial mean get a boundary of their own in front of that mean (_Gates).
 # ----------------------------------------------------------------------------------------------------------------------
 class _GradScaleState:
-    """The factor of ONE forward: written by that forward's _Boundary node, read by its _Gate node.  Never shared between forwards,
-    modules or copies of a module."""
+    """The factor of ONE boundary of ONE forward (a 0-d device tensor, or None = 1): written by that boundary's _Boundary node, read by
+    its _Gate node.  Never shared between forwards, modules or copies of a module."""
 
     def __init__(self):
-        self.scale = 1.0
+        self.scale: Optional[Tensor] = None
 
 
 class _Boundary(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mu, kinfo, sigma, state):
+    def forward(ctx, state, *outs):
         ctx.state = state
-        return mu.view_as(mu), kinfo.view_as(kinfo), sigma.view_as(sigma)
+        return tuple(t.view_as(t) for t in outs)
 
     @staticmethod
-    def backward(ctx, dmu, dkinfo, dsigma):
-        grads = [g for g in (dmu, dkinfo, dsigma) if g is not None]
-        amax = max(float(g.detach().abs().amax()) for g in grads) if grads else 0.0
-        scale = 1.0
-        if amax > 0.0 and math.isfinite(amax) and not (2.0 ** -10 <= amax <= 2.0 ** 10):
-            scale = 2.0 ** (-math.floor(math.log2(amax)) - 1)          # largest entry -> [0.5, 1)
+    def backward(ctx, *douts):
+        grads = [g for g in douts if g is not None]
+        if not grads:
+            ctx.state.scale = None
+            return (None,) + douts
+        amax = grads[0].detach().abs().amax()
+        for g in grads[1:]:
+            amax = torch.maximum(amax, g.detach().abs().amax())
+        # largest entry -> [0.5, 1) unless it already lies in [2^-10, 2^10]; everything stays on the device (no host read)
+        scale = torch.exp2(torch.clamp(-torch.floor(torch.log2(amax.clamp_min(1e-37))) - 1.0, -100.0, 100.0))
+        keep = (amax >= 2.0 ** -10) & (amax <= 2.0 ** 10) | ~torch.isfinite(amax) | (amax <= 0)
+        scale = torch.where(keep, torch.ones_like(scale), scale)
         ctx.state.scale = scale
-        if scale == 1.0:
-            return dmu, dkinfo, dsigma, None
-        return tuple(None if g is None else g * scale for g in (dmu, dkinfo, dsigma)) + (None,)
+        return (None,) + tuple(None if g is None else g * scale for g in douts)
 
 
 class _Gate(torch.autograd.Function):
@@ -353,10 +390,35 @@ class _Gate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         s = ctx.state.scale
-        if s == 1.0:
+        if s is None:
             return (None,) + grads
         inv = 1.0 / s                                                   # (a power of two: exact)
         return (None,) + tuple(None if g is None else g * inv for g in grads)
+
+
+class _Gates:
+    """The gated parameter views of one forward: one outer boundary (the network's outputs) and one inner boundary per encoder whose
+    output passes a spatial MEAN (SNet with noise_avg, KNet: their gradient chains start 1/(h*w) below the outer scale, which would push
+    the split-fp16 GEMMs' operands towards fp16's subnormals -- each such chain gets its own power of two, undone by its own gate)."""
+
+    def __init__(self, net, inner_prefixes):
+        self.outer = _GradScaleState()
+        named = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
+        views = dict(zip((k for k, _ in named), _Gate.apply(self.outer, *[p for _, p in named]))) if named else {}
+        self.inner = {}
+        for pre in inner_prefixes:
+            keys = [k for k in views if k.startswith(pre)]
+            if keys:
+                st = _GradScaleState()
+                views.update(zip(keys, _Gate.apply(st, *[views[k] for k in keys])))
+                self.inner[pre] = st
+        self.views = views
+
+    def rescaler(self, prefix: str):
+        """Identity for the last map of sub-network ``prefix`` whose backward rescales the incoming gradient for that chain (None: no
+        inner boundary for it)."""
+        st = self.inner.get(prefix)
+        return None if st is None else (lambda t: _Boundary.apply(st, t)[0])
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -371,21 +433,41 @@ def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     sf = int(sf)
     x = _prep(x, net.SNet.in_channels)
     n = x.shape[0]
-    if net.noise_cond and not net.noise_avg:
-        raise NotImplementedError("VIRAttResUNetSR training with a per-pixel variance map (noise_avg=False) is not built: the SFT layers "
-                                  "would need per-pixel modulation gradients; train with noise_avg=True (the reference's default)")
-    state = _GradScaleState()
-    named = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
-    gated = _Gate.apply(state, *[p for _, p in named]) if named else ()
+    gates = _Gates(net, (["SNet."] if net.noise_avg else []) + ["KNet."])
     # the forward below reads the modules' attributes: swap the gated views in for its duration (what torch.func.functional_call does)
-    with torch.nn.utils.stateless._reparametrize_module(net, {k: g for (k, _), g in zip(named, gated)}), torch.cuda.device(x.device):
-        sigma = torch.exp(torch.clamp(_snet(net.SNet, x), min=LOG_MIN, max=LOG_MAX))          # VIRNet.py:81
-        kinfo = _knet(net.KNet, x)                                                            # VIRNet.py:82
+    with torch.nn.utils.stateless._reparametrize_module(net, gates.views), torch.cuda.device(x.device):
+        sigma = torch.exp(torch.clamp(_snet(net.SNet, x, gates.rescaler("SNet.")), min=LOG_MIN, max=LOG_MAX))   # VIRNet.py:81
+        kinfo = _knet(net.KNet, x, gates.rescaler("KNet."))                                   # VIRNet.py:82
         parts = []
         if net.kernel_cond:
             parts.append(kinfo)
+        emap = None
         if net.noise_cond:
-            parts.append(sigma.view(n, -1).sqrt())                                            # VIRNet.py:92
+            if net.noise_avg:
+                parts.append(sigma.view(n, -1).sqrt())                                        # VIRNet.py:92
+            else:                                                                             # VIRNet.py:94: per-pixel variance map
+                emap = sigma.sqrt()
+                if sf > 1:
+                    emap = emap.repeat_interleave(sf, dim=2).repeat_interleave(sf, dim=3)     # F.interpolate(nearest, x sf)
         vec = torch.cat(parts, 1) if parts else None
-        mu = _rnet(net.RNet, x, vec, sf)
-    return _Boundary.apply(mu, kinfo, sigma, state)
+        mu = _rnet(net.RNet, x, vec, sf, emap)
+    return _Boundary.apply(gates.outer, mu, kinfo, sigma)
+
+
+def denoise_forward_nodes(net, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """VIRAttResUNet.forward (VIRNet.py:42-46) with gradients through the per-layer nodes of this module: the configurations the
+    denoiser's fused step (train.py: one autograd Function, conditioning through the head only) does not cover -- ``extra_mode`` Down /
+    Both (SFT layers fed by the per-pixel sqrt-variance map) and ``noise_avg=True``."""
+    if x.requires_grad:
+        raise RuntimeError("VIRAttResUNet: a gradient with respect to the input image is not implemented (the reference's training "
+                           "never asks for one, train_denoising_syn.py:171-184); pass x.detach()")
+    x = _prep(x, net.SNet.in_channels)
+    if net.noise_cond and net.SNet.noise_avg:
+        # the reference fails here too: a [N,C,1,1] map cannot be reflect-padded / concatenated (AttResUNet.py:150,153)
+        raise RuntimeError("VIRAttResUNet(noise_avg=True, noise_cond=True): the [N,C,1,1] variance cannot be "
+                           "padded or concatenated with the image (same failure as the reference)")
+    gates = _Gates(net, ["SNet."] if net.SNet.noise_avg else [])
+    with torch.nn.utils.stateless._reparametrize_module(net, gates.views), torch.cuda.device(x.device):
+        sigma = torch.exp(torch.clamp(_snet(net.SNet, x, gates.rescaler("SNet.")), min=LOG_MIN, max=LOG_MAX))   # VIRNet.py:43
+        mu = _rnet(net.RNet, x, None, 1, sigma.sqrt() if net.noise_cond else None)            # VIRNet.py:44-45
+    return _Boundary.apply(gates.outer, mu, sigma)
