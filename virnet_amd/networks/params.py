@@ -75,6 +75,7 @@ class ConvParam(nn.Module):
         self._packs = {}
         self._dgrads = {}
         self._thin = None
+        self._cond_dgrad = None
 
     def forward(self, *args, **kwargs):  # pragma: no cover - guard
         raise RuntimeError("ConvParam holds parameters only; the convolution runs inside libvirnet_hip "

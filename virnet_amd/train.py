@@ -144,6 +144,22 @@ def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1,
     grads.update(new)
 
 
+def _head_cond_dgrad(conv, in_chn: int, nc: int):
+    """Packing of the input-gradient conv of the head restricted to its ``nc`` conditioning channels (AttResUNet.py:153: the record is
+    [image | sqrt(sigma) | 0]; the image needs no gradient): W'[c][co][ky][kx] = W[co][in_chn + c][2-ky][2-kx], a features -> nc exit conv.
+    None when the form has no exit kernel for it (fp32 forms, nc * 9 > 32).  Cached on the layer like its other packings."""
+    if not ops._f16_family() or nc * 9 > 32 or conv.cout % 16:
+        return None
+    key = (conv.weight.data_ptr(), conv.weight._version, str(conv.weight.device), ops.conv_form(), in_chn, nc)
+    hit = getattr(conv, "_cond_dgrad", None)
+    if hit is None or hit[0] != key:
+        wd = conv.weight.detach()[:, in_chn:in_chn + nc].flip(2, 3).permute(1, 0, 2, 3).contiguous()
+        hit = (key, ops.pack_weight(wd, None))
+        conv._cond_dgrad = hit
+    pw = hit[1]
+    return pw if pw.f16 is not None else None
+
+
 def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[Tensor], reducer=None) -> Dict:
     snet, rnet = net.SNet, net.RNet
     grads: Dict = {}
@@ -193,9 +209,18 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
         rec = tape.misc["rec"]
         _conv_grads(grads, rnet.head, rec, dx, reducer=reducer)
         if tape.misc["cond"]:
-            drec, _ = ops.conv_mfma(dx, rnet.head.packed_dgrad(), want_raw=True, out_channels=32)
-            parts = [ops.pack_input_backward(drec, rnet.in_chn + c, (h, w), map_=sigma[:, c:c + 1].contiguous(), map_sqrt=True)
-                     for c in range(sigma.shape[1])]
+            nc = sigma.shape[1]
+            pw = _head_cond_dgrad(rnet.head, rnet.in_chn, nc)
+            if pw is not None:
+                # only the conditioning channels of the record gradient are needed: a features -> nc-channel exit conv with planar store
+                # (csrc/conv_exit.hip) instead of the 32-channel fp32 GEMM; a planar channel is an NHWC tensor of one channel
+                dplanar = ops.conv_f16_nchw(dx, pw, (hp, wp))
+                parts = [ops.pack_input_backward((dplanar if nc == 1 else dplanar[:, c].contiguous()).view(n, hp, wp, 1), 0, (h, w),
+                                                 map_=sigma[:, c:c + 1].contiguous(), map_sqrt=True) for c in range(nc)]
+            else:
+                drec, _ = ops.conv_mfma(dx, rnet.head.packed_dgrad(), want_raw=True, out_channels=32)
+                parts = [ops.pack_input_backward(drec, rnet.in_chn + c, (h, w), map_=sigma[:, c:c + 1].contiguous(), map_sqrt=True)
+                         for c in range(nc)]
             d_sigma_total += torch.cat(parts, 1)
     else:
         for p in rnet.parameters():

@@ -393,7 +393,9 @@ class _Gate(torch.autograd.Function):
         if s is None:
             return (None,) + grads
         inv = 1.0 / s                                                   # (a power of two: exact)
-        return (None,) + tuple(None if g is None else g * inv for g in grads)
+        live = [g for g in grads if g is not None]
+        scaled = iter(torch._foreach_mul(live, inv)) if live else iter(())      # one multi-tensor launch for the ~225 gradients
+        return (None,) + tuple(None if g is None else next(scaled) for g in grads)
 
 
 class _Gates:
