@@ -640,7 +640,17 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
   // staging the pixel tile once per workgroup, instead of 5 / 7 single-slab workgroups per tile); a lone odd slab runs by itself.
   int n3 = nb / 3, rem = nb - 3 * n3;
   if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
-  const int n2 = rem / 2, n1 = rem - 2 * n2;
+  int n2 = rem / 2, n1 = rem - 2 * n2;
+  // Launches far from filling the chip (deep levels of single images: a 64x64 x 288-channel conv is 32 tiles x 3 channel blocks = 96
+  // workgroups of 18 chunks each): one slab per workgroup triples the grid, shortens every workgroup and puts channel counts that are
+  // not multiples of 96 (160 = 3 + 2, 224 = 3 + 2 + 2) into ONE launch.  No result bit depends on the grouping.  VIRNET_F16_SPLIT_WGS:
+  // the largest 3-slab grid that is split (0 = never).
+  {
+    const char* const env_s = getenv("VIRNET_F16_SPLIT_WGS");
+    const long split_below = env_s ? atol(env_s) : 128;
+    const long tiles4 = (long)d->n * ((d->h + 3) / 4) * ((d->w + 31) / 32);
+    if (nb > 1 && tiles4 * (n3 + n2 + n1) <= split_below) { n3 = 0; n2 = 0; n1 = nb; }
+  }
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;

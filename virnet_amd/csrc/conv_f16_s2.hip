@@ -300,6 +300,13 @@ int launch(FArgs k, hipStream_t st) {
 // Slabs per workgroup: 6 (8 waves) where the count allows, then 3 / 2 / 1 with 4 waves (288 channels = 6 + 3, 160 = 3 + 2, 224 = 6 + ... 3 + 2 + 2).
 int virnet::launch_f16_s2(FArgs k, int nb, hipStream_t st) {
   int n6 = nb / 6, rem = nb - 6 * n6;
+  // Small launches (single images): with 6 slabs per workgroup a 64x64 output is 32 workgroups on a 256-CU chip (and 288 channels two
+  // such launches back to back: 48 + 36 us measured); 3-slab workgroups triple the grid and put all slabs in ONE launch.  The slab
+  // grouping does not change any result bit (channels are independent).
+  {
+    const long tiles = (long)k.N * ((k.OH + 3) / 4) * ((k.OW + 31) / 32);
+    if (n6 > 0 && tiles * n6 < 192) { n6 = 0; rem = nb; }
+  }
   if (rem == 1 && n6 >= 1) { n6 -= 1; rem = 7; }
   int n3 = rem / 3, rem2 = rem - 3 * n3;
   if (rem2 == 1 && n3 >= 1) { n3 -= 1; rem2 = 4; }
