@@ -160,3 +160,22 @@ def test_denoise_table_plumbing_cpu():
     assert [r["case"] for r in rows_n] == [1, 2, 3] and all(10.0 < r["psnr"] < 30.0 for r in rows_n)
     with pytest.raises(ValueError):
         veval.denoise_table(lambda n: n, data, "poisson")
+
+
+def test_mcmaster_noise_stream_continues_behind_cbsd68():
+    """scripts/denoising_virnet_syn.py:93,95,130: ONE generator for both datasets -- McMaster's sigma = 50 noise (probes written by the
+    reference's own generator, tests/golden/make_mcmaster_golden.py) is reproduced by replaying the CBSD68 draws from their shapes."""
+    import json
+    with open(os.path.join(GOLDEN, "mcmaster.json")) as f:
+        g = json.load(f)
+    shapes = [tuple(s) for s in g["shapes"]]
+    probes = {r["index"]: r["noise_probe"] for r in g["images"]}
+    seen = 0
+    for s, idx, noise in veval.iid_noise_stream(shapes, before=[[tuple(x) for x in g["cbsd68_shapes"]]]):
+        if s != 50:
+            continue
+        p = probes[idx]
+        assert np.array_equal(noise.reshape(-1)[:4], np.asarray(p["first"], np.float32)), idx
+        assert abs(float(noise.astype(np.float64).sum()) - p["sum"]) <= 1e-6 * max(1.0, abs(p["sum"]))
+        seen += 1
+    assert seen == 18

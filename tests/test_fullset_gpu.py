@@ -79,3 +79,32 @@ def test_set5_x4_all_seven_kernels_vs_reference_psnr():
     for k in range(7):
         assert len(per_kernel[k]) == 5
         assert abs(float(np.mean(per_kernel[k])) - g["mean_psnr_y_per_kernel"][k]) <= 0.01
+
+
+def test_mcmaster_all_18_images_sigma50_vs_reference_psnr():
+    """The script's SECOND dataset (scripts/denoising_virnet_syn.py:93): its sigma = 50 case sits behind the 3 x 68 CBSD68 draws and its own
+    sigma = 15 / 25 draws of the shared generator -- replayed from the shape lists.  500 x 500 images (not a multiple of the tile sizes)."""
+    from virnet_amd.networks import VIRAttResUNet
+    with open(os.path.join(GOLDEN, "mcmaster.json")) as f:
+        g = json.load(f)
+    assert len(g["images"]) == 18
+    net = VIRAttResUNet(**g["config"])
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}), strict=True)
+    net = net.cuda()
+    shapes = [tuple(s) for s in g["shapes"]]
+    images = {i: veval.imread_rgb_uint8(os.path.join(GOLDEN, "mcmaster", n)) for i, n in enumerate(g["names"])}
+    ref = {r["index"]: r for r in g["images"]}
+    got = []
+    for idx, gt, noisy in veval.noisy_inputs(images, shapes, 50, before=[[tuple(s) for s in g["cbsd68_shapes"]]]):
+        x = torch.from_numpy(noisy.transpose(2, 0, 1)[np.newaxis].copy())
+        with torch.no_grad():
+            mu, sigma = net(x.cuda())
+        den = veval.img_as_ubyte(mu.squeeze(0).cpu().numpy().transpose(1, 2, 0))
+        p = veval.calculate_psnr(den, gt)
+        r = ref[idx]
+        assert g["names"][idx] == r["name"]
+        assert abs(p - r["psnr"]) <= 0.01, (r["name"], p, r["psnr"])
+        assert abs(float(mu.double().mean()) - r["mu_mean"]) <= 1e-4 and abs(float(mu.abs().max()) - r["mu_absmax"]) <= 1e-3
+        got.append(p)
+    assert len(got) == 18
+    assert abs(float(np.mean(got)) - g["mean_psnr"]) <= 0.01, (np.mean(got), g["mean_psnr"])

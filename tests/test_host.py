@@ -112,11 +112,17 @@ def test_missing_library_fails_loudly(monkeypatch):
 def test_wx4_shape_rule(monkeypatch):
     """Which launches take the Winograd-along-x kernel (ops.wx4_shape_ok): enough output channels, tiles reasonably filled, and a launch
     that fills the chip -- the headline batch on every level, a single 256 x 256 image only on the level where the two kernels are level."""
-    for k in ("VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS"):
+    for k in ("VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS"):
         monkeypatch.delenv(k, raising=False)
     assert all(ops.wx4_shape_ok(32, s, s, c) for s, c in ((256, 96), (128, 192), (64, 288), (256, 64)))      # bench shape: all levels + SNet
     assert ops.wx4_shape_ok(64, 32, 32, 288) and ops.wx4_shape_ok(16, 64, 64, 224)                            # configs[1] level 2, SISR level 2
-    assert ops.wx4_shape_ok(1, 256, 256, 96) and not ops.wx4_shape_ok(1, 128, 128, 192) and not ops.wx4_shape_ok(1, 64, 64, 288)
+    assert ops.wx4_shape_ok(1, 256, 256, 96) and not ops.wx4_shape_ok(1, 64, 64, 288) and not ops.wx4_shape_ok(1, 32, 32, 288)
+    # launches below a round of 96-channel workgroups still take it (8-row tiles, fewer slabs per workgroup) while single-slab work fills
+    # the chip and the channel count is whole 96-blocks (SISR's 160 / 224 stay on the direct kernel's one-launch single-slab form)
+    assert ops.wx4_shape_ok(1, 128, 128, 192) and ops.wx4_shape_ok(1, 128, 128, 96) and not ops.wx4_shape_ok(1, 128, 128, 160)
+    monkeypatch.setenv("VIRNET_WX4_MIN_SLAB_WGS", "1000000000")
+    assert not ops.wx4_shape_ok(1, 128, 128, 192)
+    monkeypatch.delenv("VIRNET_WX4_MIN_SLAB_WGS")
     assert not ops.wx4_shape_ok(32, 256, 256, 32)                                                             # thin layers stay on conv_f16
     assert not ops.wx4_shape_ok(64, 17, 33, 96)                                                               # 2 x 2 tiles for 561 pixels: fill 0.27
     monkeypatch.setenv("VIRNET_WX4_MIN_WGS", "0")                                                             # form independent of the launch size

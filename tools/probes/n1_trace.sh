@@ -14,6 +14,6 @@ for r in tail:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = 0 if prev is None else s - prev
     prev = e
-    name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")[:48]
+    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:48]
     print(f"{name:50s} grid {int(r['Grid_Size_X'])//max(1,int(r['Workgroup_Size_X'])):6d} wg {int(r['Workgroup_Size_X']):4d}  {(e-s)/1000:7.1f} us  gap {gap/1000:6.1f}")
 PY

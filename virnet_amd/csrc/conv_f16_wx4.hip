@@ -726,18 +726,36 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
   // slabs per workgroup: 3 where the count allows, the remainder in 2s (160 = 3 + 2, 224 = 3 + 2 + 2), a lone odd slab by itself
   int n3 = nb / 3, rem = nb - 3 * n3;
   if (rem == 1 && n3 >= 1) { n3 -= 1; rem = 4; }
-  const int n2 = rem / 2, n1 = rem - 2 * n2;
+  int n2 = rem / 2, n1 = rem - 2 * n2;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  }
+  // Launches that leave CUs empty (the deep levels of a single image: 128x128x192 is 64 8-row tiles x 2 channel blocks): fewer slabs per
+  // workgroup -- the smallest count that still fits ONE round of one workgroup per CU in ONE launch (measured, profiles/r04_probes.md 7:
+  // q1 3/2/1 slabs 0.052 / 0.046 / 0.051 ms, q2 0.062 / 0.084 (two launches) / 0.047, r1 0.049 / 0.041 / 0.037).  No result bit depends on
+  // the grouping.  VIRNET_WX4_NREP=1|2|3 pins it (3 = the default grouping).
+  {
+    const char* const nrep_env = getenv("VIRNET_WX4_NREP");
+    int want = nrep_env ? atoi(nrep_env) : 0;
+    if (want == 0) {
+      const long tiles8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32);
+      const int groups3 = n3 + n2 + n1;
+      if (tiles8 * groups3 < n_cu) {
+        for (int c = 1; c <= 2 && want == 0; ++c)
+          if (nb % c == 0 && tiles8 * (nb / c) <= n_cu) want = c;
+      }
+    }
+    if (want == 1) { n3 = 0; n2 = 0; n1 = nb; }
+    else if (want == 2) { n3 = 0; n2 = nb / 2; n1 = nb - 2 * n2; }
+  }
   // Tile form per launch: 16-row tiles / 8 waves / one workgroup per CU (this file) or 8-row tiles / 4 waves / two per CU
   // (conv_f16_wx4h.hip).  Measured (profiles/r04_probes.md): on launches that fill the chip many times over both forms run the socket
   // at its 1400 W power cap and the 16-row form is 3-6 % ahead (fewer barriers and weight pieces per MFMA) -- except with two-slab
   // workgroups (64 channels), where the 8-row form is 4 % ahead; on launches of a few hundred workgroups the 8-row form wins whenever
   // its finer grain saves a round: a lone 8-row workgroup takes ~0.55 of a 16-row one, a co-resident pair ~1.04.
   // VIRNET_WX4_ROWS=8|16 pins the form (A/B runs, tests).
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-  }
   // VIRNET_DETERMINISTIC=1 (or the older VIRNET_WX4_MIN_WGS=0): results must not depend on the launch size -> one tile form for all.
   const char* const rows_env = getenv("VIRNET_WX4_ROWS");
   const char* const det_env = getenv("VIRNET_DETERMINISTIC");

@@ -43,24 +43,33 @@ def calculate_psnr(im1: np.ndarray, im2: np.ndarray, border: int = 0) -> float:
     return float("inf") if mse == 0 else 20.0 * math.log10(255.0 / math.sqrt(mse))
 
 
-def iid_noise_stream(shapes: Sequence[Tuple[int, int]], sigmas: Iterable[int] = IID_SIGMAS, seed: int = NOISE_SEED):
-    """Yield (sigma, image index, noise[h,w,3] float32) in the reference's order for the FIRST dataset of the script.
+def iid_noise_stream(shapes: Sequence[Tuple[int, int]], sigmas: Iterable[int] = IID_SIGMAS, seed: int = NOISE_SEED,
+                     before: Sequence[Sequence[Tuple[int, int]]] = ()):
+    """Yield (sigma, image index, noise[h,w,3] float32) in the reference's order for one dataset of the script.
 
     The script shares ONE generator across all cases (scripts/denoising_virnet_syn.py:95,130): sigma=50 on CBSD68 is reached
-    only after the sigma=15 and sigma=25 draws over all 68 images, so the stream is replayed from the image shapes."""
+    only after the sigma=15 and sigma=25 draws over all 68 images, so the stream is replayed from the image shapes.  ``before``: the
+    shape lists of the datasets the script walks EARLIER (McMaster comes after all three CBSD68 cases, scripts/denoising_virnet_syn.py:93,
+    110): their draws are replayed and discarded."""
+    sigmas = tuple(sigmas)
     rng = np.random.default_rng(seed=seed)
+    for earlier in before:
+        for _ in sigmas:
+            for (h, w) in earlier:
+                rng.standard_normal(size=(h, w, 3))
     for sigma in sigmas:
         for idx, (h, w) in enumerate(shapes):
             noise = rng.standard_normal(size=(h, w, 3)) * (np.ones([h, w], dtype=np.float32) * (sigma / 255.0))[:, :, np.newaxis]
             yield sigma, idx, noise.astype(np.float32)
 
 
-def noisy_inputs(images: dict, shapes: Sequence[Tuple[int, int]], sigma: int) -> List[Tuple[int, np.ndarray, np.ndarray]]:
+def noisy_inputs(images: dict, shapes: Sequence[Tuple[int, int]], sigma: int,
+                 before: Sequence[Sequence[Tuple[int, int]]] = ()) -> List[Tuple[int, np.ndarray, np.ndarray]]:
     """For the images given as {index in the sorted dataset: uint8 HWC}, the (index, gt, noisy float32 HWC) triples of case `sigma`.
 
-    `im_noisy = img_as_float32(gt) + noise`, NOT clipped (scripts/denoising_virnet_syn.py:131)."""
+    `im_noisy = img_as_float32(gt) + noise`, NOT clipped (scripts/denoising_virnet_syn.py:131).  ``before``: see iid_noise_stream."""
     out = []
-    for s, idx, noise in iid_noise_stream(shapes):
+    for s, idx, noise in iid_noise_stream(shapes, before=before):
         if s == sigma and idx in images:
             gt = images[idx]
             if gt.shape[:2] != tuple(shapes[idx]):

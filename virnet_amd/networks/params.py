@@ -40,8 +40,8 @@ class ConvParam(nn.Module):
     def packed(self) -> ops.PackedWeight:
         """Packed weight for the MFMA kernel, rebuilt when the parameter storage or version changed."""
         form = ops.conv_form()
-        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device),
-               None if self.bias is None else (self.bias.data_ptr(), self.bias._version))
+        w, b = self.weight, self.bias
+        key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
         hit = self._packs.get(form)
         if hit is None or hit[0] != key:
             hit = (key, ops.pack_weight(self.weight, self.bias, transposed=self.transposed, stride=self.stride))

@@ -99,7 +99,7 @@ DEFAULT_CONV_FORM = "wx4"
 
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
-_KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS",
+_KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
           "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
@@ -120,6 +120,7 @@ class forward_scope:
             tls.form_override = self._form
         if getattr(tls, "form_override", None) is not None:        # (a nested scope keeps the enclosing scope's override)
             tls.scope_env["VIRNET_CONV_FORM"] = tls.form_override
+        tls.scope_env["#parsed"] = {}                              # values derived from the knobs, computed once per scope (conv_form, wx4 thresholds)
         tls.stream_cache = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         return self
 
@@ -137,8 +138,20 @@ def _env(name: str, default=None):
     return os.environ.get(name, default)
 
 
-def conv_form() -> str:
-    import os
+def _parsed(key: str, make):
+    """Inside a forward_scope: ``make()`` evaluated once per scope (a single-image forward asks ~9 knob questions per launch);
+    outside: evaluated per call, as the kernel-level tests expect."""
+    snap = getattr(nat.tls, "scope_env", None)
+    if snap is None:
+        return make()
+    cache = snap["#parsed"]
+    v = cache.get(key)
+    if v is None:
+        v = cache[key] = make()
+    return v
+
+
+def _conv_form_now() -> str:
     form = _env("VIRNET_CONV_FORM")
     if form is None:
         legacy = _env("VIRNET_WINOGRAD")
@@ -148,8 +161,17 @@ def conv_form() -> str:
     return form
 
 
+def conv_form() -> str:
+    return _parsed("form", _conv_form_now)
+
+
 def _f16_family() -> bool:
     return conv_form() in ("f16x3", "bf16", "wx4")
+
+
+def _wx4_rule():
+    return (int(_env("VIRNET_WX4_MIN_COUT", "64")), int(_env("VIRNET_WX4_MIN_TILES", "1")), float(_env("VIRNET_WX4_MIN_FILL", "0.6")),
+            _env("VIRNET_DETERMINISTIC", "0") == "1", int(_env("VIRNET_WX4_MIN_WGS", "128")), int(_env("VIRNET_WX4_MIN_SLAB_WGS", "192")))
 
 
 def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
@@ -162,15 +184,22 @@ def wx4_shape_ok(n: int, h: int, w: int, cout: int) -> bool:
     bitwise batch independence (tests/test_e2e_gpu.py holds both).  Inside the Winograd form the library additionally picks the tile
     height per launch size (csrc/conv_f16_wx4.hip: 16-row tiles / one workgroup per CU, or 8-row tiles / two per CU for launches of a
     few hundred workgroups and the 64-channel layers); the deterministic switch pins that as well."""
-    if cout < int(_env("VIRNET_WX4_MIN_COUT", "64")):          # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
+    min_cout, min_tiles, min_fill, deterministic, min_wgs, min_slab_wgs = _parsed("wx4_rule", _wx4_rule)
+    if cout < min_cout:                                     # (64 channels = two-slab workgroups: 5 % ahead of conv_f16 on the SNet convs; 32: behind)
         return False
     th, tw = (h + 15) // 16, (w + 31) // 32
     fill = (h * w) / float(th * 16 * tw * 32)
-    if th * tw < int(_env("VIRNET_WX4_MIN_TILES", "1")) or fill < float(_env("VIRNET_WX4_MIN_FILL", "0.6")):
+    if th * tw < min_tiles or fill < min_fill:
         return False
-    if _env("VIRNET_DETERMINISTIC", "0") == "1":           # one kernel form whatever the batch size (the library pins its tile form too)
+    if deterministic:                                       # one kernel form whatever the batch size (the library pins its tile form too)
         return True
-    return n * th * tw * ((cout + 95) // 96) >= int(_env("VIRNET_WX4_MIN_WGS", "128"))
+    if n * th * tw * ((cout + 95) // 96) >= min_wgs:
+        return True
+    # below that: the 8-row form with fewer slabs per workgroup (the library picks the count) when that still gives the chip a round of
+    # single-slab work -- the deep levels of a single image (128x128x192: 64 tiles x 6 slabs)
+    # (channel counts that are not whole 96-channel blocks -- SISR's 160 / 224 -- would take two or three launches there: the direct
+    # kernel's single-slab form does them in one; measured end to end: 256^2 1.27 -> 1.21 ms, SISR x4 1.49 -> 1.56 without this condition)
+    return cout % 96 == 0 and n * ((h + 7) // 8) * tw * (cout // 32) >= min_slab_wgs
 
 
 def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
