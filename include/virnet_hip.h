@@ -282,6 +282,27 @@ int virnet_chsplit_s2(const float* x, int n, int h, int w, int c, int in_act, fl
 size_t virnet_conv_wgrad_f16_s2_scratch_bytes(int n, int oh, int ow, int chi, int clo);
 int virnet_conv_wgrad_f16_s2(const void* hi_t, const void* lo_t, float* dw, float* scratch, int n, int oh, int ow, int chi, int clo,
                              int cin, int cout, int mode, int bf16, void* stream);
+/* T emission (training step): a stride-1 3x3 NHWC convolution with a single-store epilogue (y_raw XOR y_act; residual and / or mask
+ * allowed; no output SFT, no in_mul for the Winograd form) can write, besides its NHWC tensor, the channel-major T image of that
+ * tensor -- exactly what a virnet_chsplit pass over it would produce, without reading it back (the 74 re-layout passes of a training
+ * step were 13 % of it) -- and per-workgroup channel sums of it (the bias gradient of the conv whose output gradient this tensor is).
+ *   t_out : virnet_chsplit_bytes(n, h, w, cout) bytes whose rows 0 / h+1 and pad segments are ALREADY zero (the kernel writes the image
+ *           rows and, inside them, zeros for tile pixels beyond w; it never touches the pads) -- bf16 != 0: one bf16 plane
+ *   act   : T holds lrelu(y, slope) instead of y (the staging transform of the NEXT conv, AttResUNet.py:55, whose weight gradient reads it)
+ *   col   : NULL, or virnet_conv_emit_ok()'s nblk * cout floats: partial sums col[(cb * nblk + blk) * 32 + ch] of y over the pixels of
+ *           workgroup-wave blk; virnet_colpart_reduce adds them into db (zero db first)
+ * virnet_conv_emit_ok: 1 when `d` can run with emission in that form (0: virnet_conv_f16 / virnet_conv_bf16, 1: virnet_conv_wx4). */
+typedef struct virnet_t_emit {
+  void* t_out;
+  float* col;
+  int act;
+  float slope;
+  int bf16;
+} virnet_t_emit;
+int virnet_conv_emit_ok(const virnet_conv_desc* d, int form, int* nblk);
+int virnet_conv_f16_emit(const virnet_conv_desc* d, const virnet_t_emit* te, int bf16_operands, void* stream);
+int virnet_conv_wx4_emit(const virnet_conv_desc* d, const virnet_t_emit* te, void* stream);
+int virnet_colpart_reduce(const float* col, float* db, long nblk, int ncb, int cvalid, void* stream);
 /* Backward of the SFT pre-activation a = lrelu(x*mul + add, slope) with per-image [n][c] vectors (AttResUNet.py:54-58), given da = dL/da:
  * du = da * lrelu'(x*mul+add);  dx = du*mul (+ res, the skip gradient, may be NULL);  dmul[n][c] += sum_p du*x;  dadd[n][c] += sum_p du
  * (zero dmul / dadd first).  NHWC tensors of n images x hw pixels x c channels (c % 4 == 0). */

@@ -37,6 +37,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class TEmit(C.Structure):
+    _fields_ = [("t_out", C.c_void_p), ("col", C.c_void_p), ("act", C.c_int), ("slope", C.c_float), ("bf16", C.c_int)]
+
+
 class PackDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("vec", C.c_void_p), ("map", C.c_void_p), ("out", C.c_void_p),
@@ -132,6 +136,10 @@ SYMBOLS = [
     ("virnet_conv_wgrad_f16_s2_scratch_bytes", C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("virnet_conv_wgrad_f16_s2", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_conv_emit_ok", C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int)]),
+    ("virnet_conv_f16_emit", C.c_int, [C.POINTER(ConvDesc), C.POINTER(TEmit), C.c_int, C.c_void_p]),
+    ("virnet_conv_wx4_emit", C.c_int, [C.POINTER(ConvDesc), C.POINTER(TEmit), C.c_void_p]),
+    ("virnet_colpart_reduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_zero_stuff2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_space_to_depth2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -40,8 +40,13 @@ using namespace virnet;
 //   AttResUNet.tail, AttResUNet.py:139,173; DnCNN.conv_last, DnCNN.py:29 + VIRNet.py:43; KernelNet.tail, KNet.py:49).
 // BF = 1: the bf16-operand variant (BASELINE configs[4]'s training precision): ONE product per MAC on v_mfma_f32_32x32x16_bf16, operands
 // rounded to bf16 while they are staged (weights when they are packed), no low halves anywhere; everything else is the same kernel.
-template <int MREP, int NREP, int EPI, int BF = 0>
+// TE = 1 (training step): the epilogue also EMITS the channel-major image of the stored tensor that the weight-gradient GEMM contracts
+// over (FArgs::t_out; wgrad_f16.hip's T) and the tile's channel sums -- what a virnet_chsplit pass over the stored tensor would produce,
+// without reading it back.  The reader's items become 8 CONSECUTIVE pixels (one 16-byte T unit per channel and plane) instead of 8
+// pixels eight apart; the NHWC stores cover 128 contiguous bytes per 8 lanes either way.
+template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
+  static_assert(!TE || (MREP == 2 && EPI < 4), "T emission: 8-row tiles (8 items per thread), single-store epilogues");
   constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
   constexpr int NPIECE = NPIX * 2;                 // (pixel, 8-channel half) staging pieces of one chunk
   constexpr int PPT = (NPIECE + 255) / 256;
@@ -317,15 +322,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
   constexpr int TPIX = 144, NIT = MREP * 4;          // 8 pixels per pass
-  constexpr int TREG = MREP * 32 * TPIX;             // one slab of one wave; two regions per wave (ping-pong)
+  constexpr int TREG = MREP * 32 * TPIX + (TE ? 128 : 0);   // one slab of one wave; two regions per wave (ping-pong)
   static_assert(4 * 2 * TREG <= 81920, "turn-around regions: two workgroups per CU");   // (launch<> sizes LDS for the larger of the two)
   char* const tbuf = smem + wave * (2 * TREG);
   const int cq = lane & 7, psub = lane >> 3;
+  // LDS slot of tile pixel p (TE: 16 more bytes per 8 pixels, so that the lanes of one read -- pixels 8 apart -- keep the 36-dword spacing)
+  auto pixoff = [](int p) { return p * TPIX + (TE ? (p >> 3) * 16 : 0); };
   unsigned eoff[NIT];
   bool eok[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int pix = it * 8 + psub;
+    const int pix = TE ? psub * 8 + it : it * 8 + psub;
     const int oy = oy0 + wave * MREP + (pix >> 5), ox = ox0 + (pix & 31);
     eok[it] = oy < a.H && ox < a.W;
     eoff[it] = (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1)) * (unsigned)C + (unsigned)(nbase + cq * 4);
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(tbuf + region * TREG + (mr * 32 + l31) * TPIX + (8 * g + 4 * lhi) * 4) =
+        *reinterpret_cast<f32x4*>(tbuf + region * TREG + pixoff(mr * 32 + l31) + (8 * g + 4 * lhi) * 4) =
             f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
   };
   auto mask4 = [&](f32x4 v, f32x4 m) {
@@ -399,17 +406,50 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       const f32x4 b4 = bias4[nr] * hb;
       f32x4 tv[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) tv[it] = *reinterpret_cast<const f32x4*>(tbuf + (nr & 1) * TREG + (it * 8 + psub) * TPIX + cq * 16);
+      for (int it = 0; it < NIT; ++it) tv[it] = *reinterpret_cast<const f32x4*>(tbuf + (nr & 1) * TREG + pixoff(TE ? psub * 8 + it : it * 8 + psub) + cq * 16);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         f32x4 v = tv[it] * inv4[nr] + b4;
         if (MASK) v = mask4(v, EPI == 3 ? mv[it] : op1[HOIST ? nr : 0][it]);
         if (RES) v += EPI == 3 ? rv[it] : op1[HOIST ? nr : 0][it];
         v = lrelu4(v, slope_eff);
+        if (TE) tv[it] = v;
         // (the slab offset rides in the instruction's immediate, NOT in soffset: hipcc 7.2 schedules a v_pk_* write of the data
         // registers straight behind a 16-B buffer store with an SGPR offset -- the hazard that needs a wait state -- and the odd
         // elements of the stored quad come out wrong)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
+      }
+      if constexpr (TE) {
+        // thread (cq, psub) holds 8 consecutive pixels of tile row wave*MREP + (psub >> 2), x-segment psub & 3, for 4 channels
+        const int trow = oy0 + wave * MREP + (psub >> 2);
+        const int cbg = (nbase >> 5) + nr;                      // 32-channel block of the stored tensor
+        char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + (psub & 3) + 1)) * 512 + cq * 64;
+        f32x4 cs = zero4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float e8[8];
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const float sv = eok[it] ? tv[it][c] : 0.f;       // (tile pixels beyond the image are zero in T, as chsplit writes them)
+            cs[c] += sv;
+            e8[it] = a.t_act ? fmaxf(sv, sv * a.t_slope) : sv;
+          }
+          u32x4 hi, lo;
+          t_units(e8, BF != 0, hi, lo);
+          if (trow < a.H) {
+            *reinterpret_cast<u32x4*>(tb + c * 16) = hi;
+            if (!BF) *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + c * 16) = lo;
+          }
+        }
+        if (a.t_col) {                                          // wave's channel sums: the 8 psub lanes of a channel quad, then one row per wave
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            cs[c] += __shfl_xor(cs[c], 8);
+            cs[c] += __shfl_xor(cs[c], 16);
+            cs[c] += __shfl_xor(cs[c], 32);
+          }
+          if (psub == 0) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 4 + wave) * 32 + cq * 4) = cs;
+        }
       }
       if (nr == 0) TSTAMP(7);
     }
@@ -457,14 +497,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #endif
 }
 
-template <int MREP, int NREP, int EPI, int BF = 0>
+template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);       // K loop: pixel tiles + weight stages
-  constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144);                  // epilogue: two turn-around regions per wave
+  constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144 + (TE ? 128 : 0));   // epilogue: two turn-around regions per wave
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static unsigned long long attr_done = 0;
-  auto kern = conv_f16_kernel<MREP, NREP, EPI, BF>;
+  auto kern = conv_f16_kernel<MREP, NREP, EPI, BF, TE>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16): %s", hipGetErrorString(e));
@@ -557,9 +597,22 @@ extern "C" int virnet_pack_bf16_weight(const float* w, int dgrad, int cout, int 
   return virnet::check_launch("pack_bf16 launch");
 }
 
-static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf);
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te = nullptr);
 
 extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) { return conv_f16_impl(d, stream, 0); }
+
+static bool f16_emit_shape_ok(const virnet_conv_desc* d) {
+  return d && d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC && d->cout > 0 && d->cout % 32 == 0 && d->n_pad == d->cout &&
+         !d->mul && ((d->y_raw != nullptr) != (d->y_act != nullptr));
+}
+
+extern "C" int virnet_conv_f16_emit(const virnet_conv_desc* d, const virnet_t_emit* te, int bf16_operands, void* stream) {
+  VIRNET_REQUIRE(d != nullptr && te != nullptr && te->t_out != nullptr, "virnet_conv_f16_emit: NULL descriptor / T buffer");
+  VIRNET_REQUIRE(f16_emit_shape_ok(d), "virnet_conv_f16_emit: T emission needs the stride-1 3x3 NHWC conv with ONE stored tensor and no output SFT");
+  VIRNET_REQUIRE((bf16_operands != 0) == (te->bf16 != 0), "virnet_conv_f16_emit: the T image follows the operand form (bf16 with bf16 operands)");
+  VIRNET_REQUIRE(!te->act || (te->slope >= 0.f && te->slope <= 1.f), "virnet_conv_f16_emit: slope=%g outside [0,1]", te->slope);
+  return conv_f16_impl(d, stream, bf16_operands ? 1 : 0, te);
+}
 
 // bf16-operand variant of the stride-1 3x3 NHWC convolution (one product per MAC, fp32 accumulation): wpack from virnet_pack_bf16_weight
 extern "C" int virnet_conv_bf16(const virnet_conv_desc* d, void* stream) {
@@ -569,7 +622,7 @@ extern "C" int virnet_conv_bf16(const virnet_conv_desc* d, void* stream) {
   return conv_f16_impl(d, stream, 1);
 }
 
-static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
   if (d->ks == 1 && d->epi == VIRNET_EPI_CONVT) {                // UpBlock.upsampler + bridge (AttResUNet.py:80,84-87): conv_f16_pw.hip
@@ -649,8 +702,9 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
     const char* const env_s = getenv("VIRNET_F16_SPLIT_WGS");
     const long split_below = env_s ? atol(env_s) : 128;
     const long tiles4 = (long)d->n * ((d->h + 3) / 4) * ((d->w + 31) / 32);
-    if (nb > 1 && tiles4 * (n3 + n2 + n1) <= split_below) { n3 = 0; n2 = 0; n1 = nb; }
+    if (nb > 1 && tiles4 * (n3 + n2 + n1) <= split_below && !te) { n3 = 0; n2 = 0; n1 = nb; }
   }
+  if (te) virnet::t_emit_args(k, te, d->w, d->cout, (int)(tiles8 * 4));      // (emission runs on 8-row tiles whatever the grid: 4 waves per tile)
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
@@ -658,6 +712,14 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
     kk.NP = groups * nrep * 32;
     int mrep = (tiles8 * groups >= 1024) ? 2 : 1;
     if (forced_m == 1 || forced_m == 2) mrep = forced_m;
+    if (te) {
+#define VIRNET_F16_TE(N_, E_) if (nrep == N_ && epi == E_) return bf ? launch<2, N_, E_, 1, 1>(kk, st) : launch<2, N_, E_, 0, 1>(kk, st);
+#define VIRNET_F16_TEN(N_) VIRNET_F16_TE(N_, 0) VIRNET_F16_TE(N_, 1) VIRNET_F16_TE(N_, 2) VIRNET_F16_TE(N_, 3)
+      VIRNET_F16_TEN(3) VIRNET_F16_TEN(2) VIRNET_F16_TEN(1)
+#undef VIRNET_F16_TEN
+#undef VIRNET_F16_TE
+      return virnet::set_error("virnet_conv_f16_emit: no emitting kernel for nrep=%d epi=%d", nrep, epi);
+    }
 #define VIRNET_F16_CASE(M_, N_)                                          \
     if (mrep == M_ && nrep == N_) {                                      \
       if (bf) {                                                          \
@@ -681,4 +743,15 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf) {
   if (int rc = run(3, 0, n3)) return rc;
   if (int rc = run(2, 3 * n3, n2)) return rc;
   return run(1, 3 * n3 + 2 * n2, n1);
+}
+
+// form 0: conv_f16 / conv_bf16 (8-row tiles, 4 waves); form 1: conv_wx4 (16-row tiles, 8 waves)
+extern "C" int virnet_conv_emit_ok(const virnet_conv_desc* d, int form, int* nblk) {
+  if (!f16_emit_shape_ok(d) || (form != 0 && form != 1)) return 0;
+  if (form == 1 && (d->in_mul || d->cin_pad < 32)) return 0;
+  const long th = form == 1 ? 16 : 8, nw = form == 1 ? 8 : 4;
+  const long blocks = (long)d->n * ((d->h + th - 1) / th) * ((d->w + 31) / 32) * nw;
+  if (blocks >= (1L << 30)) return 0;
+  if (nblk) *nblk = (int)blocks;
+  return 1;
 }

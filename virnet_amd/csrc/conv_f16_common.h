@@ -45,7 +45,45 @@ struct FArgs {
   float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
   long long* tlog;
   int* range_flag;         // sticky device flag (virnet_set_range_flag) set when a staged operand leaves fp16's range, or NULL
+  // T emission (training step; kernels instantiated with TE = 1): besides the NHWC tensor the epilogue writes the channel-major
+  // fp16 hi|lo (or bf16) image wgrad_f16.hip contracts over -- T[n][H+2][t_cb][t_npl][t_nseg][32 ch][8 px], pixel x at index x + 8 --
+  // of the STORED value (t_act: of lrelu(stored, t_slope), the staging transform of the conv that will consume it), and per
+  // (workgroup, wave) channel sums of the stored value (the bias gradient's partial sums: t_col[(cb * t_nblk + tile * waves + wave) * 32 + ch]).
+  char* t_out;
+  float* t_col;
+  int t_cb, t_npl, t_nseg, t_nblk, t_act;
+  float t_slope;
 };
+
+// segments per row of T (wgrad_f16.hip: t_nseg -- the pixels rounded up to whole 64-pixel steps, 32 for narrow images, + one pad segment each side)
+inline int t_nseg_of(int w) { return w <= 32 ? 6 : 8 * ((w + 63) / 64) + 2; }
+
+// fills the T-emission fields of a kernel argument block from the public descriptor pair
+inline void t_emit_args(FArgs& k, const virnet_t_emit* te, int w, int cout, int nblk) {
+  k.t_out = static_cast<char*>(te->t_out); k.t_col = te->col;
+  k.t_cb = cout / 32; k.t_npl = 2; k.t_nseg = t_nseg_of(w); k.t_nblk = nblk;      // (a bf16 image keeps the two-plane stride and leaves plane 1 unused: chsplit_kernel<1>)
+  k.t_act = te->act; k.t_slope = te->slope;
+}
+
+// 8 fp32 -> the 16-byte T unit(s) of wgrad_f16.hip: fp16 hi / lo (chsplit_kernel's split) or one bf16 plane
+__device__ __forceinline__ void t_units(const float (&v)[8], bool bf, u32x4& hi, u32x4& lo) {
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (bf) {
+      const __bf16 hb = (__bf16)v[e];
+      h[e] = __builtin_bit_cast(unsigned short, hb);
+      l[e] = 0;
+    } else {
+      const _Float16 hh = (_Float16)v[e];
+      const _Float16 ll = (_Float16)(v[e] - (float)hh);
+      h[e] = __builtin_bit_cast(unsigned short, hh);
+      l[e] = __builtin_bit_cast(unsigned short, ll);
+    }
+  }
+  hi = u32x4{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16), (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16)};
+  lo = u32x4{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16), (unsigned)l[4] | ((unsigned)l[5] << 16), (unsigned)l[6] | ((unsigned)l[7] << 16)};
+}
 
 // One 1-KB piece (64 lanes x 16 B) global -> LDS without a register round trip, as a MUBUF instruction (buffer_load_dwordx4 ... lds):
 // descriptor over the weight image, lane offset in a register, piece offset scalar.  Against global_load_lds (a FLAT instruction with a

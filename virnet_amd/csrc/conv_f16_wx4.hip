@@ -49,8 +49,13 @@ constexpr int WX_CHUNK_BYTES = 36 * 1024;
 
 // PRE: what the conv applies to x while it is staged -- 0: nothing; 1: lrelu(x, in_slope); 2: lrelu(x*in_mul+in_add, in_slope), the SFT
 // pre-activation of AttResUNet.py:54-55 with per-(image, channel) vectors.
-template <int NREP, int EPI, int PRE>
+// TE = 1 (training step): the epilogue also emits the channel-major T image of the stored tensor and its channel sums (FArgs::t_out /
+// t_col; conv_f16.hip has the same variant).  The epilogue reader's items become 8 CONSECUTIVE pixels of one row -- thread = (row of 16,
+// x-segment of 4, channel quad) instead of (pixel column, row parity, channel quad) with row pairs as items -- so that a thread holds
+// one 16-byte T unit per channel and plane and no second LDS pass is needed; every NHWC store still covers 128 contiguous bytes per 8 lanes.
+template <int NREP, int EPI, int PRE, int TE = 0>
 __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
+  static_assert(!TE || EPI < 4, "T emission: single-store epilogues");
   constexpr int NB = 32 * NREP;
   constexpr int NDMA = 12 * NREP;                  // 1-KB pieces of one weight stage: [jt][dy][slab][hi|lo]
   constexpr int USTAGE = NDMA * 1024;
@@ -436,11 +441,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // serves the operand loads and the stores (buffer instructions; an item outside the image gets an out-of-range offset: loads 0,
   // stores nothing).
   const int cq = tid & 7, px = (tid >> 3) & 31, prow = tid >> 8;
+  const int te_row = tid >> 5, te_xq = (tid >> 3) & 3;       // TE mapping: tile row 0..15, x-segment 0..3 (items = its 8 pixels)
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int oy = oy0 + 2 * it + prow, ox = ox0 + px;
+    const int oy = TE ? oy0 + te_row : oy0 + 2 * it + prow, ox = TE ? ox0 + te_xq * 8 + it : ox0 + px;
     yoff[it] = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * C + nbase + cq * 4) * 4u : 0x80000000u;
   }
   if constexpr (EPF) op1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI == 1 ? a.res : a.mask) + img_off), 0, a.H * a.W * C * 4, 0x00020000);
@@ -484,7 +490,17 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const int r_q = (3 + (pk & 1)) * WX_XBLK + pxt * 144 + cq * 16;
   const int r_e = 5 * WX_XBLK + pxt * 144 + cq * 16;
   const float ck = (float)(1 << pk), ek = pk == 3 ? 1.f : 0.f;
+  const int te_base = (te_row >> 2) * 6 * WX_XBLK + ((te_row & 3) * 8) * 144 + cq * 16;   // TE: the thread's row (row block, row in block)
   auto xread = [&](int it) {                                // row = 2*it + prow: row block it>>1, row-in-block (it&1)*2 + prow
+    if constexpr (TE) {                                     // pixel te_xq*8 + it of row te_row: x-tile te_xq*2 + (it>>2), pixel-in-tile it&3
+      const int pkk = it & 3;
+      const int b0 = te_base + (te_xq * 2 + (it >> 2)) * 144;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xb + b0 + ((pkk == 0) ? 0 : (pkk == 2) ? 2 : 1) * WX_XBLK);
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + b0 + (3 + (pkk & 1)) * WX_XBLK);
+      f32x4 r = p + (float)(1 << pkk) * qv;
+      if (pkk == 3) r += *reinterpret_cast<const f32x4*>(xb + b0 + 5 * WX_XBLK);
+      return r;
+    }
     const int base = (it >> 1) * 6 * WX_XBLK + (((it & 1) * 2 + prow) * 8) * 144;
     const f32x4 p = *reinterpret_cast<const f32x4*>(xb + base + r_p);
     const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + base + r_q);
@@ -554,6 +570,37 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       for (int it = 0; it < NIT; ++it)
         // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+      if constexpr (TE) {
+        const int trow = oy0 + te_row;
+        const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
+        char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + te_xq + 1)) * 512 + cq * 64;
+        f32x4 cs = zero4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float e8[8];
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const float sv = yoff[it] != 0x80000000u ? tv[it][c] : 0.f;      // (tile pixels beyond the image are zero in T)
+            cs[c] += sv;
+            e8[it] = a.t_act ? fmaxf(sv, sv * a.t_slope) : sv;
+          }
+          u32x4 hi, lo;
+          t_units(e8, false, hi, lo);
+          if (trow < a.H) {
+            *reinterpret_cast<u32x4*>(tb + c * 16) = hi;
+            *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + c * 16) = lo;
+          }
+        }
+        if (a.t_col) {                                      // wave's channel sums (its 8 lanes per channel quad), one row per wave
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            cs[c] += __shfl_xor(cs[c], 8);
+            cs[c] += __shfl_xor(cs[c], 16);
+            cs[c] += __shfl_xor(cs[c], 32);
+          }
+          if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 8 + wave) * 32 + cq * 4) = cs;
+        }
+      }
       if (nr == 0) TSTAMP(7);
       if (nr + 1 < NREP) wx_lds_barrier();
     }
@@ -594,14 +641,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   TSTAMP(3);
 }
 
-template <int NREP, int EPI, int PRE>
+template <int NREP, int EPI, int PRE, int TE = 0>
 int launch_wx4(FArgs k, hipStream_t st) {
   constexpr int LDS_K = WX_VBYTES + 2 * 12 * NREP * 1024;
   constexpr int LDS_E = 24 * WX_XBLK;
   constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 2 * 32 * NREP * 4;      // + the channel block's inverse scales and biases
   static_assert(LDS <= 160 * 1024, "one workgroup per CU");
   static unsigned long long attr_done = 0;
-  auto kern = conv_wx4_kernel<NREP, EPI, PRE>;
+  auto kern = conv_wx4_kernel<NREP, EPI, PRE, TE>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wx4): %s", hipGetErrorString(e));
@@ -690,7 +737,20 @@ extern "C" int virnet_pack_wx4_weight(const float* w, int dgrad, int cout, int c
   return virnet::check_launch("pack_wx4 launch");
 }
 
-extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
+static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t_emit* te);
+
+extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) { return conv_wx4_impl(d, stream, nullptr); }
+
+extern "C" int virnet_conv_wx4_emit(const virnet_conv_desc* d, const virnet_t_emit* te, void* stream) {
+  VIRNET_REQUIRE(d != nullptr && te != nullptr && te->t_out != nullptr, "virnet_conv_wx4_emit: NULL descriptor / T buffer");
+  int nblk = 0;
+  VIRNET_REQUIRE(virnet_conv_emit_ok(d, 1, &nblk), "virnet_conv_wx4_emit: T emission needs the stride-1 3x3 NHWC conv with ONE stored tensor, no output SFT and no in_mul");
+  VIRNET_REQUIRE(!te->bf16, "virnet_conv_wx4_emit: the Winograd form has split-fp16 operands (T = fp16 hi | lo)");
+  VIRNET_REQUIRE(!te->act || (te->slope >= 0.f && te->slope <= 1.f), "virnet_conv_wx4_emit: slope=%g outside [0,1]", te->slope);
+  return conv_wx4_impl(d, stream, te);
+}
+
+static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t_emit* te) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_wx4: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_wx4: x / wpack is NULL");
   VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC, "virnet_conv_wx4: only the stride-1 3x3 NHWC conv (ks=%d stride=%d epi=%d)",
@@ -773,11 +833,20 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) {
     const double t8 = 1.04 * (double)full + (tail == 0 ? 0.0 : tail <= n_cu ? 0.55 : 1.04);
     return t8 < t16;
   };
+  if (te) virnet::t_emit_args(k, te, d->w, d->cout, d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * 8);
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
+    if (te) {                                               // emission: 16-row tiles whatever the launch size
+#define VIRNET_WX4_TE(N_, E_) if (nrep == N_ && epi == E_) return pre == 1 ? launch_wx4<N_, E_, 1, 1>(kk, st) : launch_wx4<N_, E_, 0, 1>(kk, st);
+#define VIRNET_WX4_TEN(N_) VIRNET_WX4_TE(N_, 0) VIRNET_WX4_TE(N_, 1) VIRNET_WX4_TE(N_, 2) VIRNET_WX4_TE(N_, 3)
+      VIRNET_WX4_TEN(3) VIRNET_WX4_TEN(2) VIRNET_WX4_TEN(1)
+#undef VIRNET_WX4_TEN
+#undef VIRNET_WX4_TE
+      return virnet::set_error("virnet_conv_wx4_emit: no emitting kernel for nrep=%d epi=%d pre=%d", nrep, epi, pre);
+    }
     if (half_tiles_for(nrep, groups)) return virnet::launch_wx4h(kk, nrep, epi, pre, st);
 #define VIRNET_WX4_EPI(N_, E_)                                                                                               \
     if (epi == E_) return pre == 2 ? launch_wx4<N_, E_, 2>(kk, st) : pre == 1 ? launch_wx4<N_, E_, 1>(kk, st) : launch_wx4<N_, E_, 0>(kk, st);

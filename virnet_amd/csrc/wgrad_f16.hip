@@ -684,3 +684,10 @@ extern "C" size_t virnet_conv_wgrad_f16_s2_scratch_bytes(int n, int oh, int ow, 
   const Plan p = make_plan(n, oh, ow, ncob, ncib, 2);
   return (size_t)p.split * 9 * ncob * 32 * ncib * 32 * sizeof(float);
 }
+
+extern "C" int virnet_colpart_reduce(const float* col, float* db, long nblk, int ncb, int cvalid, void* stream) {
+  VIRNET_REQUIRE(col && db && nblk > 0 && ncb > 0 && cvalid >= 1 && cvalid <= ncb * 32, "virnet_colpart_reduce: bad arguments (nblk=%ld ncb=%d cvalid=%d)", nblk, ncb, cvalid);
+  const int slices = (int)(nblk / 64 < 1 ? 1 : nblk / 64 > 64 ? 64 : nblk / 64);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(ncb, slices), dim3(256), 0, static_cast<hipStream_t>(stream), col, db, nblk, cvalid, ncb);
+  return virnet::check_launch("colpart_reduce launch");
+}

@@ -64,10 +64,16 @@ def set_launch_timer(t: Optional[LaunchTimer]) -> None:
     _TIMER = t
 
 
-def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct") -> None:
+def _launch_conv(d: "nat.ConvDesc", flops: float, what: str, form: str = "direct", te: Optional["nat.TEmit"] = None) -> None:
     lib = nat.load()
     fn = {"wino": lib.virnet_conv_wino, "f16x3": lib.virnet_conv_f16, "bf16": lib.virnet_conv_bf16, "direct": lib.virnet_conv_mfma,
           "wx4": lib.virnet_conv_wx4}[form]
+    if te is not None:                                   # the same launch + T emission (csrc: TE = 1 instantiations)
+        tep = C.byref(te)
+        if form == "wx4":
+            fn = lambda dd, st: lib.virnet_conv_wx4_emit(dd, tep, st)
+        else:
+            fn = lambda dd, st: lib.virnet_conv_f16_emit(dd, tep, int(form == "bf16"), st)
     if _TIMER is None:
         nat.check(fn(C.byref(d), nat.stream_handle()), what)
         return
@@ -99,7 +105,7 @@ DEFAULT_CONV_FORM = "wx4"
 
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
-_KNOBS = ("VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
+_KNOBS = ("VIRNET_T_EMIT", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
           "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
@@ -406,15 +412,58 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
     return pw
 
 
+@dataclass
+class TImage:
+    """Channel-major fp16 hi|lo (or bf16) image of an NHWC tensor -- the operand layout of the f16-pipe weight gradient
+    (csrc/wgrad_f16.hip) -- as written by ``virnet_chsplit`` or emitted by a convolution's epilogue; ``db``: the tensor's channel sums
+    (bias gradient) when they were asked for."""
+    buf: Tensor
+    n: int
+    h: int
+    w: int
+    c: int
+    bf16: bool
+    db: Optional[Tensor] = None
+    pooled: bool = False
+
+
+_T_POOL: dict = {}
+
+
+def t_acquire(n: int, h: int, w: int, c: int, bf16: bool, device: torch.device) -> TImage:
+    """A T buffer whose pad rows / segments are zero: emitting kernels write only the image rows, so buffers of one geometry are
+    recycled (``t_release``) instead of being zero-filled per use (a fill is 40 % of the re-layout pass the emission replaces)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, n, h, w, c)
+    free = _T_POOL.setdefault(key, [])
+    buf = free.pop() if free else torch.zeros(nat.load().virnet_chsplit_bytes(n, h, w, c), dtype=torch.uint8, device=device)
+    return TImage(buf, n, h, w, c, bf16, None, True)
+
+
+def t_release(t: Optional[TImage]) -> None:
+    if t is not None and t.pooled and t.buf is not None:
+        dev = t.buf.device
+        _T_POOL.setdefault((dev.index, torch.cuda.current_stream(dev).cuda_stream, t.n, t.h, t.w, t.c), []).append(t.buf)
+        t.buf = None
+
+
+def t_emission_enabled() -> bool:
+    """VIRNET_T_EMIT=0 keeps the separate re-layout passes (A/B runs)."""
+    return _env("VIRNET_T_EMIT", "1") != "0"
+
+
 def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Tensor] = None,
               mul: Optional[Tensor] = None, add: Optional[Tensor] = None, want_raw: bool = True,
               want_act: bool = False, slope: float = 0.2, in_slope: Optional[float] = None,
               in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None, mask: Optional[Tensor] = None,
-              mask_slope: float = 0.2, out_channels: Optional[int] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+              mask_slope: float = 0.2, out_channels: Optional[int] = None, emit: Optional[dict] = None):
     """NHWC conv (or transposed conv when ``pw.transposed``) -> (raw, act), each NHWC or None.
 
     ``in_slope`` (with optional per-(image, channel) ``in_mul``/``in_add``): the conv consumes
-    ``leaky_relu(x*in_mul+in_add, in_slope)`` -- the pre-activation of AttResUNet.py:55 -- applied while x is staged."""
+    ``leaky_relu(x*in_mul+in_add, in_slope)`` -- the pre-activation of AttResUNet.py:55 -- applied while x is staged.
+
+    ``emit`` (training step) = dict(act=None | slope, colsum=None | channels): the conv is asked to emit, next to its stored tensor,
+    that tensor's T image (of ``lrelu(y, act)`` when ``act`` is given) and optionally its channel sums; the call then returns
+    ``(raw, act, TImage | None)`` -- None when this launch cannot emit (form / shape), the caller re-lays the tensor itself."""
     _dev_check(x, "x")
     n, h, w, c = x.shape
     if c != pw.cin_pad:
@@ -455,6 +504,9 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         elif want in ("f16x3", "bf16", "wx4") and pw.f16 is not None and pw.cout % 32 == 0:
             form = "f16x3"
     wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16, "bf16": pw.bf16, "wx4": pw.wx4}[form]
+    if emit is not None and form == "wx4" and (n * ((h + 15) // 16) * ((w + 31) // 32) * ((pw.cout + 95) // 96) < 128 or in_mul is not None
+                                               or c < 32) and pw.f16 is not None:
+        form, wimg = "f16x3", pw.f16                     # (emission runs the 16-row Winograd tiles only where they fill the chip)
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,
@@ -462,8 +514,30 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
                      in_slope=0.0 if in_slope is None else in_slope, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
     # algorithmic FLOPs = 2*MAC over the REAL channels; the transposed conv does 4*cout columns per input pixel
     flops = 2.0 * n * h * w * pw.cin_real * pw.cout * 4 if pw.transposed else 2.0 * n * oh * ow * pw.cin_real * pw.cout * pw.ks ** 2
-    _launch_conv(d, flops, {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16", "bf16": "conv_bf16", "wx4": "conv_wx4"}[form], form)
-    return raw, act
+    what = {"direct": "conv_mfma", "wino": "conv_wino", "f16x3": "conv_f16", "bf16": "conv_bf16", "wx4": "conv_wx4"}[form]
+    if emit is None:
+        _launch_conv(d, flops, what, form)
+        return raw, act
+    timg = None
+    nblk = C.c_int(0)
+    lib = nat.load()
+    if (t_emission_enabled() and form in ("f16x3", "bf16", "wx4") and not pw.transposed and stride == 1
+            and lib.virnet_conv_emit_ok(C.byref(d), int(form == "wx4"), C.byref(nblk))):
+        timg = t_acquire(n, oh, ow, cstore, form == "bf16", x.device)
+        col = None
+        ncol = emit.get("colsum")
+        if ncol is not None:
+            col = _workspace("emit_col", nblk.value * cstore * 4, x.device)
+            timg.db = torch.zeros(ncol, dtype=torch.float32, device=x.device)
+        slope_t = emit.get("act")
+        te = nat.TEmit(t_out=nat.ptr(timg.buf), col=nat.ptr(col), act=int(slope_t is not None), slope=0.0 if slope_t is None else slope_t,
+                       bf16=int(form == "bf16"))
+        _launch_conv(d, flops, what + "(+T)", form, te)
+        if col is not None:
+            nat.check(lib.virnet_colpart_reduce(nat.ptr(col), nat.ptr(timg.db), nblk.value, cstore // 32, ncol, nat.stream_handle()), "colpart_reduce")
+    else:
+        _launch_conv(d, flops, what, form)
+    return raw, act, timg
 
 
 def conv_mfma_nchw(x: Tensor, pw: PackedWeight, crop_hw: Tuple[int, int], *, op: int = nat.NCHW_PLAIN,
@@ -741,11 +815,13 @@ def sft_apply(raw: Tensor, rec: Tensor, chan0: int, nchan: int, step: int, att) 
 # ----------------------------------------------------------------------------------------------------------------------
 def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: int = 1, transposed: bool = False,
                in_slope: Optional[float] = None, in_mul: Optional[Tensor] = None, in_add: Optional[Tensor] = None,
-               bias_channels: Optional[int] = None):
+               bias_channels: Optional[int] = None, xt: Optional[TImage] = None, yt: Optional[TImage] = None):
     """Weight gradient in the reference layout (OIHW, or IOHW 2x2 for the transposed conv) from NHWC forward input ``x`` and
     NHWC output gradient ``dy`` (for the transposed conv: the space-to-depth gradient).  With ``bias_channels`` the bias gradient
     (sum of ``dy`` over pixels, first ``bias_channels`` channels) is returned too -- ``(dw, db)`` -- fused into the f16 path's pass
-    over ``dy`` where that path runs, a ``virnet_colsum`` launch otherwise."""
+    over ``dy`` where that path runs, a ``virnet_colsum`` launch otherwise.  ``xt`` / ``yt``: T images of the (staged) input / of ``dy``
+    that a convolution's epilogue already emitted (``conv_mfma(emit=...)``): the f16 path then skips its re-layout pass over that operand
+    (``yt.db`` is the bias gradient)."""
     _dev_check(x, "x"); _dev_check(dy, "dy")
     n, h, w, cx = x.shape
     cy = dy.shape[3]
@@ -758,7 +834,7 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
             and _env("VIRNET_WGRAD_FORM", "f16") != "f32"):
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
         return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
-                               bias_channels=bias_channels)
+                               bias_channels=bias_channels, xt=xt, yt=yt)
     if not transposed and stride == 2 and ks == 3 and _wgrad_s2_ok(h // 2, cx):
         return _conv_wgrad_f16_s2(x, dy, weight_shape, 0, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
                                   bias_channels=bias_channels)
@@ -829,27 +905,44 @@ def _workspace(tag: str, nbytes: int, device: torch.device) -> Tensor:
 
 
 def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_slope, in_mul, in_add, *, bf16: bool,
-                    bias_channels: Optional[int] = None):
+                    bias_channels: Optional[int] = None, xt: Optional[TImage] = None, yt: Optional[TImage] = None):
     """Stride-1 3x3 weight gradient on the f16 pipe (csrc/wgrad_f16.hip): both operands are first re-laid channel-major as fp16
     hi/lo planes (``virnet_chsplit``, which also applies the forward conv's staging transform to ``x``), then contracted over pixels."""
     lib = nat.load()
     n, h, w, cx = x.shape
     cy = dy.shape[3]
     st = nat.stream_handle()
-    xt = _workspace("wgrad_xt", lib.virnet_chsplit_bytes(n, h, w, cx), x.device)
-    yt = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, h, w, cy), x.device)
+    for t, cc, nm in ((xt, cx, "xt"), (yt, cy, "yt")):     # an emitted image is used only when it is THE image this call would build
+        if t is not None and ((t.n, t.h, t.w, t.c) != (n, h, w, cc) or t.buf is None):
+            raise ValueError(f"conv_wgrad: {nm} is a T image of {(t.n, t.h, t.w, t.c)}, expected {(n, h, w, cc)}")
+    if xt is not None and xt.bf16 != bf16:
+        xt = None                                           # (emitted by a conv of the other operand form: re-lay it)
+    if yt is not None and yt.bf16 != bf16:
+        yt = None
+    if yt is not None and bias_channels is not None and (yt.db is None or yt.db.numel() != bias_channels):
+        yt = None                                           # (no channel sums came with it: take the pass that produces them)
     timed = _TIMER is not None
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    nat.check(lib.virnet_chsplit(nat.ptr(x), n, h, w, cx, int(in_slope is not None), 0.0 if in_slope is None else in_slope,
-                                 nat.ptr(in_mul), nat.ptr(in_add), int(bf16), nat.ptr(xt), None, None, 0, st), "chsplit")
+    if xt is None:
+        xbuf = _workspace("wgrad_xt", lib.virnet_chsplit_bytes(n, h, w, cx), x.device)
+        nat.check(lib.virnet_chsplit(nat.ptr(x), n, h, w, cx, int(in_slope is not None), 0.0 if in_slope is None else in_slope,
+                                     nat.ptr(in_mul), nat.ptr(in_add), int(bf16), nat.ptr(xbuf), None, None, 0, st), "chsplit")
+    else:
+        xbuf = xt.buf
     db = col = None
-    if bias_channels is not None:
-        db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
-        col = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, h, w, cy), x.device)
-    nat.check(lib.virnet_chsplit(nat.ptr(dy), n, h, w, cy, 0, 0.0, None, None, int(bf16), nat.ptr(yt), nat.ptr(col), nat.ptr(db),
-                                 0 if bias_channels is None else bias_channels, st), "chsplit")
+    if yt is None:
+        ybuf = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, h, w, cy), x.device)
+        if bias_channels is not None:
+            db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
+            col = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, h, w, cy), x.device)
+        nat.check(lib.virnet_chsplit(nat.ptr(dy), n, h, w, cy, 0, 0.0, None, None, int(bf16), nat.ptr(ybuf), nat.ptr(col), nat.ptr(db),
+                                     0 if bias_channels is None else bias_channels, st), "chsplit")
+    else:
+        ybuf = yt.buf
+        db = yt.db if bias_channels is not None else None
+    xt, yt = xbuf, ybuf
     scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_scratch_bytes(n, h, w, cx, cy), x.device)
     nat.check(lib.virnet_conv_wgrad_f16(nat.ptr(xt), nat.ptr(yt), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16), st), "conv_wgrad_f16")
     if timed:
