@@ -202,7 +202,7 @@ def _hip_lrelu_masks(net, x, h, w):
     out = [nchw(a) > 0 for a in tape.snet["acts"]]                      # DnCNN.py:23,27 (post-activation: the sign survives)
     for kind, _mod, x_in, aux in tape.misc["order"]:
         if kind == "block":                                             # AttResUNet.py:55 on the block input, :58 on conv1's output
-            out += [nchw(x_in) > 0, nchw(aux) > 0]
+            out += [nchw(x_in) > 0, nchw(aux[0]) > 0]                    # (aux = (f1a, emitted operand images))
     return out
 
 

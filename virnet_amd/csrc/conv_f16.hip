@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
         const int cbg = (nbase >> 5) + nr;                      // 32-channel block of the stored tensor
         char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + (psub & 3) + 1)) * 512 + cq * 64;
         f32x4 cs = zero4;
+        u32x4 uh[4], ul[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float e8[8];
@@ -434,11 +435,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
             cs[c] += sv;
             e8[it] = a.t_act ? fmaxf(sv, sv * a.t_slope) : sv;
           }
-          u32x4 hi, lo;
-          t_units(e8, BF != 0, hi, lo);
-          if (trow < a.H) {
-            *reinterpret_cast<u32x4*>(tb + c * 16) = hi;
-            if (!BF) *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + c * 16) = lo;
+          t_units(e8, BF != 0, uh[c], ul[c]);
+        }
+        // lane cq writes the units of its channels 4cq .. 4cq+3: 64 contiguous bytes per lane and plane, 512 per 8 lanes.  (Measured:
+        // a DPP quad transpose that makes every single store instruction lane-contiguous costs more than it saves -- training step
+        // 24.9 -> 27.7 ms fp32-class, 17.2 -> 18.5 bf16, profiles/r04_probes.md 8.)
+        if (trow < a.H) {
+          char* const tq = tb - cq * 64;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(tq + (4 * cq + i) * 16) = uh[i];
+            if (!BF) *reinterpret_cast<u32x4*>(tq + (size_t)a.t_nseg * 512 + (4 * cq + i) * 16) = ul[i];
           }
         }
         if (a.t_col) {                                          // wave's channel sums: the 8 psub lanes of a channel quad, then one row per wave

@@ -575,6 +575,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
         char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + te_xq + 1)) * 512 + cq * 64;
         f32x4 cs = zero4;
+        u32x4 uh[4], ul[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float e8[8];
@@ -584,11 +585,14 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
             cs[c] += sv;
             e8[it] = a.t_act ? fmaxf(sv, sv * a.t_slope) : sv;
           }
-          u32x4 hi, lo;
-          t_units(e8, false, hi, lo);
-          if (trow < a.H) {
-            *reinterpret_cast<u32x4*>(tb + c * 16) = hi;
-            *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + c * 16) = lo;
+          t_units(e8, false, uh[c], ul[c]);
+        }
+        if (trow < a.H) {
+          char* const tq = tb - cq * 64;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(tq + (4 * cq + i) * 16) = uh[i];
+            *reinterpret_cast<u32x4*>(tq + (size_t)a.t_nseg * 512 + (4 * cq + i) * 16) = ul[i];
           }
         }
         if (a.t_col) {                                      // wave's channel sums (its 8 lanes per channel quad), one row per wave

@@ -504,9 +504,11 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         elif want in ("f16x3", "bf16", "wx4") and pw.f16 is not None and pw.cout % 32 == 0:
             form = "f16x3"
     wimg = {"direct": pw.w, "wino": pw.wino, "f16x3": pw.f16, "bf16": pw.bf16, "wx4": pw.wx4}[form]
-    if emit is not None and form == "wx4" and (n * ((h + 15) // 16) * ((w + 31) // 32) * ((pw.cout + 95) // 96) < 128 or in_mul is not None
-                                               or c < 32) and pw.f16 is not None:
-        form, wimg = "f16x3", pw.f16                     # (emission runs the 16-row Winograd tiles only where they fill the chip)
+    if (emit is not None and form == "wx4" and pw.f16 is not None and (in_mul is not None or c < 32 or (
+            n * ((h + 15) // 16) * ((w + 31) // 32) * ((pw.cout + 95) // 96) < 128 and _env("VIRNET_DETERMINISTIC", "0") != "1"
+            and _env("VIRNET_WX4_MIN_WGS") != "0"))):
+        form, wimg = "f16x3", pw.f16                     # (emission runs the 16-row Winograd tiles only where they fill the chip --
+                                                         #  unless the form is pinned: bitwise batch independence)
     d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(wimg), bias=nat.ptr(pw.bias), res=nat.ptr(res), mul=nat.ptr(mul),
                      add=nat.ptr(add), mask=nat.ptr(mask), mask_slope=mask_slope, in_mul=nat.ptr(in_mul), in_add=nat.ptr(in_add),
                      y_raw=nat.ptr(raw), y_act=nat.ptr(act), n=n, h=h, w=w, cin_pad=c, cout=cstore, n_pad=pw.n_pad, nrep=pw.nrep, ks=pw.ks,

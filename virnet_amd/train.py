@@ -42,6 +42,13 @@ def _thin(conv, x, crop, **kw):
     return ops.conv3x3_thin(x, conv.packed_thin(), crop, **kw) if conv.cout <= 4 else ops.conv_mfma_nchw(x, conv.packed(), crop, **kw)
 
 
+def _conv3(x, pw, emit, **kw):
+    """ops.conv_mfma -> (raw, act, T image or None) whether or not an emission was asked for."""
+    if emit is None:
+        return ops.conv_mfma(x, pw, **kw) + (None,)
+    return ops.conv_mfma(x, pw, emit=emit, **kw)
+
+
 def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
     snet, rnet = net.SNet, net.RNet
     if snet.noise_avg:
@@ -51,47 +58,59 @@ def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
     x = _prep(x, snet.in_channels)
     n, _, h, w = x.shape
     tape = _Tape()
+    # T emission: a conv whose output is the (staged) input of a stride-1 3x3 conv writes that conv's weight-gradient operand image
+    # from its own epilogue (ops.conv_mfma(emit=...)); `None` in the tape = not emitted, the backward re-lays the tensor (virnet_chsplit)
+    PLAIN, ACT02 = dict(act=None, colsum=None), dict(act=0.2, colsum=None)
+    if _side_stream(x.device) is not None:                # (images would cross streams and pools: the second-stream mode re-lays its operands)
+        PLAIN = ACT02 = None
     # ---- SNet (networks/DnCNN.py:37-44)
     rec_s = ops.pack_input(x, h, w)
-    acts = []
-    _, cur = ops.conv_mfma(rec_s, snet.conv1.packed(), want_raw=False, want_act=True, slope=0.25)
-    acts.append(cur)
+    acts, acts_t = [], []
+    _, cur, t = _conv3(rec_s, snet.conv1.packed(), PLAIN, want_raw=False, want_act=True, slope=0.25)
+    acts.append(cur); acts_t.append(t)
     mids = [snet.mid_layer[k] for k in sorted(snet.mid_layer.keys(), key=int)]
     for conv in mids:
-        _, cur = ops.conv_mfma(cur, conv.packed(), want_raw=False, want_act=True, slope=0.25)
-        acts.append(cur)
+        _, cur, t = _conv3(cur, conv.packed(), PLAIN, want_raw=False, want_act=True, slope=0.25)
+        acts.append(cur); acts_t.append(t)
     sigma = _thin(snet.conv_last, cur, (h, w), op=nat.NCHW_EXPCLAMP, clamp=(LOG_MIN, LOG_MAX))
-    tape.snet = dict(rec=rec_s, acts=acts, mids=mids, sigma=sigma)
+    tape.snet = dict(rec=rec_s, acts=acts, acts_t=acts_t, mids=mids, sigma=sigma)
     # ---- RNet (networks/AttResUNet.py:141-175)
     m = 1 << (rnet.depth - 1)
     hp, wp = _ceil_to(h, m), _ceil_to(w, m)
     cond = net.noise_cond and rnet.extra_mode == "input"
     rec = ops.pack_input(x, hp, wp, map_=sigma if cond else None, map_sqrt=True)
-    xcur, _ = ops.conv_mfma(rec, rnet.head.packed(), want_raw=True)
+    # what consumes a residual-stream tensor decides the image its producer emits: a block's conv1 stages lrelu(x, 0.2) (AttResUNet.py:55),
+    # the tail the raw tensor (:173); the stride-2 / transposed convs' weight gradients take other layouts (no emission)
+    down_levels = [list(lvl.body) for lvl in rnet.down_path]
+    up_levels = [list(up.body) for up in rnet.up_path]
+    xcur, _, xcur_t = _conv3(rec, rnet.head.packed(), ACT02 if down_levels[0] else None, want_raw=True)
     bridges = []
-    order = []                                            # ("block", blk, x_in, f1a) / ("down", conv, x_in) / ("up", conv, x_in)
-    for ii, lvl in enumerate(rnet.down_path):
-        for blk in lvl.body:
-            _, f1a = ops.conv_mfma(xcur, blk.conv1.packed(), in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
-            out, _ = ops.conv_mfma(f1a, blk.conv2.packed(), res=xcur, want_raw=True)
-            order.append(("block", blk, xcur, f1a))
-            xcur = out
+    order = []                 # ("block", blk, x_in, (f1a, T(lrelu x_in), T(f1a))) / ("down", conv, x_in, None) / ("up", conv, x_in, bridge index)
+
+    def block(blk, xin, xin_t, next_spec):
+        _, f1a, f1a_t = _conv3(xin, blk.conv1.packed(), PLAIN, in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
+        out, _, out_t = _conv3(f1a, blk.conv2.packed(), next_spec if PLAIN is not None else None, res=xin, want_raw=True)
+        order.append(("block", blk, xin, (f1a, xin_t, f1a_t)))
+        return out, out_t
+
+    for ii, body in enumerate(down_levels):
+        for bi, blk in enumerate(body):
+            xcur, xcur_t = block(blk, xcur, xcur_t, ACT02 if bi + 1 < len(body) else None)
         if ii + 1 < len(rnet.down_path):
             bridges.append(xcur)
-            out, _ = ops.conv_mfma(xcur, lvl.downsampler.packed(), stride=2, want_raw=True)
-            order.append(("down", lvl.downsampler, xcur, None))
-            xcur = out
+            out, _ = ops.conv_mfma(xcur, rnet.down_path[ii].downsampler.packed(), stride=2, want_raw=True)
+            order.append(("down", rnet.down_path[ii].downsampler, xcur, None))
+            xcur, xcur_t = out, None
     for jj, up in enumerate(rnet.up_path):
         out, _ = ops.conv_mfma(xcur, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True)
         order.append(("up", up.upsampler, xcur, len(bridges) - 1 - jj))
-        xcur = out
-        for blk in up.body:
-            _, f1a = ops.conv_mfma(xcur, blk.conv1.packed(), in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
-            out, _ = ops.conv_mfma(f1a, blk.conv2.packed(), res=xcur, want_raw=True)
-            order.append(("block", blk, xcur, f1a))
-            xcur = out
+        xcur, xcur_t = out, None
+        body = up_levels[jj]
+        for bi, blk in enumerate(body):
+            last = bi + 1 == len(body)
+            xcur, xcur_t = block(blk, xcur, xcur_t, (PLAIN if jj + 1 == len(rnet.up_path) else None) if last else ACT02)
     mu = _thin(rnet.tail, xcur, (h, w), op=nat.NCHW_ADD, res=x)
-    tape.misc = dict(rec=rec, x_last=xcur, order=order, nbridges=len(bridges), hw=(h, w), hpwp=(hp, wp), cond=cond)
+    tape.misc = dict(rec=rec, x_last=xcur, x_last_t=xcur_t, order=order, nbridges=len(bridges), hw=(h, w), hpwp=(hp, wp), cond=cond)
     return mu, sigma, tape
 
 
@@ -113,28 +132,34 @@ def _side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
     return _SIDE[idx]
 
 
-def _wgrad_pair(conv, x_in: Tensor, dy: Tensor, stride: int, in_slope: Optional[float], cvalid: Optional[int]) -> Dict:
-    """{weight: dW[, bias: db]} of one conv; the bias gradient rides on the weight-gradient's pass over dy where it can."""
-    if conv.bias is None:
-        return {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope)}
-    dw, db = ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope,
-                            bias_channels=conv.cout if cvalid is None else cvalid)
-    return {conv.weight: dw, conv.bias: db}
+def _wgrad_pair(conv, x_in: Tensor, dy: Tensor, stride: int, in_slope: Optional[float], cvalid: Optional[int], xt=None, yt=None) -> Dict:
+    """{weight: dW[, bias: db]} of one conv; the bias gradient rides on the weight-gradient's pass over dy where it can.
+    ``xt`` / ``yt``: operand images a conv's epilogue already emitted (ops.TImage), returned to the pool here."""
+    kw = dict(xt=xt, yt=yt) if (stride == 1 and (xt is not None or yt is not None)) else {}
+    try:
+        if conv.bias is None:
+            return {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope, **kw)}
+        dw, db = ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope,
+                                bias_channels=conv.cout if cvalid is None else cvalid, **kw)
+        return {conv.weight: dw, conv.bias: db}
+    finally:
+        ops.t_release(xt)
+        ops.t_release(yt)
 
 
 def _conv_grads(grads: Dict, conv, x_in: Tensor, dy: Tensor, *, stride: int = 1, in_slope: Optional[float] = None,
-                cvalid: Optional[int] = None, reducer=None) -> None:
+                cvalid: Optional[int] = None, reducer=None, xt=None, yt=None) -> None:
     """dW, db of one conv from its forward input and output gradient (NHWC); handed to the gradient reducer at once (DDP runs)."""
     side = _side_stream(dy.device)
     if side is None:
-        new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid)
+        new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid, xt, yt)
         if reducer is not None:
             reducer.push(new)
     else:
         main = torch.cuda.current_stream(dy.device)
         side.wait_stream(main)                              # dy (and x_in) are complete on the main stream up to here
         with torch.cuda.stream(side):
-            new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid)
+            new = _wgrad_pair(conv, x_in, dy, stride, in_slope, cvalid, xt, yt)
             if reducer is not None:
                 reducer.push(new)                           # bucket copies + all-reduce start behind the wgrad kernels, on THEIR stream
         for t in (x_in, dy):
@@ -172,18 +197,36 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
         dmu = dmu.detach().contiguous()
         # ---- tail: mu = conv(x_last)[crop] + x_in  (AttResUNet.py:173)
         g16 = ops.pack_input(dmu, hp, wp, zero_pad=True)                       # gradient record, zero beyond the crop
-        _conv_grads(grads, rnet.tail, tape.misc["x_last"], g16, reducer=reducer)
-        dx, _ = ops.conv_mfma(g16, rnet.tail.packed_dgrad(), want_raw=True)
+        _conv_grads(grads, rnet.tail, tape.misc["x_last"], g16, reducer=reducer, xt=tape.misc.get("x_last_t"))
+        # every gradient tensor that is the dY of a stride-1 conv's weight gradient leaves its producer with that operand image and
+        # its channel sums (the bias gradient): dx_t travels with dx
+        order = tape.misc["order"]
+
+        emitting = _side_stream(dmu.device) is None
+
+        def dy_spec(c):
+            return dict(act=None, colsum=c) if emitting else None
+
+        def emit_for(idx):          # the consumer of the gradient that flows INTO order[idx] (None: no stride-1 weight gradient takes it as dY)
+            if idx < 0:
+                return dy_spec(rnet.head.cout)                                  # the head's weight gradient
+            return dy_spec(order[idx][1].conv2.cout) if order[idx][0] == "block" else None   # (stride-2 / transposed: other layouts)
+
+        last = len(order) - 1
+        dx, _, dx_t = _conv3(g16, rnet.tail.packed_dgrad(), emit_for(last), want_raw=True)
         nb = tape.misc["nbridges"]
         dbridge: List[Optional[Tensor]] = [None] * nb
-        for kind, mod, x_in, aux in reversed(tape.misc["order"]):
+        for oi in range(last, -1, -1):
+            kind, mod, x_in, aux = order[oi]
+            nxt = emit_for(oi - 1)
             if kind == "block":                                                 # AttResBlock, AttResUNet.py:48-60
-                f1a = aux
-                _conv_grads(grads, mod.conv2, f1a, dx, reducer=reducer)
-                d_f1, _ = ops.conv_mfma(dx, mod.conv2.packed_dgrad(), mask=f1a, mask_slope=0.2, want_raw=True)
-                _conv_grads(grads, mod.conv1, x_in, d_f1, in_slope=0.2, reducer=reducer)
-                dx, _ = ops.conv_mfma(d_f1, mod.conv1.packed_dgrad(), mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
+                f1a, xin_t, f1a_t = aux
+                _conv_grads(grads, mod.conv2, f1a, dx, reducer=reducer, xt=f1a_t, yt=dx_t)
+                d_f1, _, d_f1_t = _conv3(dx, mod.conv2.packed_dgrad(), dy_spec(mod.conv1.cout), mask=f1a, mask_slope=0.2, want_raw=True)
+                _conv_grads(grads, mod.conv1, x_in, d_f1, in_slope=0.2, reducer=reducer, xt=xin_t, yt=d_f1_t)
+                dx, _, dx_t = _conv3(d_f1, mod.conv1.packed_dgrad(), nxt, mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
             elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
+                ops.t_release(dx_t); dx_t = None
                 dbridge[aux] = dx
                 side = _side_stream(dx.device)
                 main = torch.cuda.current_stream(dx.device)
@@ -200,14 +243,15 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
                     for g in new.values():
                         g.record_stream(main)
                 grads.update(new)
-                dx = ops.convt_dgrad(dx, mod.packed_dgrad())
+                dx = ops.convt_dgrad(dx, mod.packed_dgrad())                    # (the stride-2 kernel does not emit: the next block re-lays this one)
             else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
+                ops.t_release(dx_t); dx_t = None                                # (its weight gradient takes the column-phase layout)
                 _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer)
                 nb -= 1
-                dx, _ = ops.conv_mfma(ops.zero_stuff2(dx), mod.packed_dgrad(), res=dbridge[nb], want_raw=True)
+                dx, _, dx_t = _conv3(ops.zero_stuff2(dx), mod.packed_dgrad(), nxt, res=dbridge[nb], want_raw=True)
         # ---- head (AttResUNet.py:153-155): weights, and the gradient flowing into sqrt(sigma) through the conditioning channel
         rec = tape.misc["rec"]
-        _conv_grads(grads, rnet.head, rec, dx, reducer=reducer)
+        _conv_grads(grads, rnet.head, rec, dx, reducer=reducer, yt=dx_t)
         if tape.misc["cond"]:
             nc = sigma.shape[1]
             pw = _head_cond_dgrad(rnet.head, rnet.in_chn, nc)
@@ -229,13 +273,16 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
     inside = (sigma > float(torch.tensor(LOG_MIN).exp())) & (sigma < float(torch.tensor(LOG_MAX).exp()))
     dv = (d_sigma_total * sigma * inside).contiguous()                           # few-channel map: host-side glue
     g16 = ops.pack_input(dv, h, w, zero_pad=True)
-    acts, mids = tape.snet["acts"], tape.snet["mids"]
-    _conv_grads(grads, snet.conv_last, acts[-1], g16, reducer=reducer)
-    dpre, _ = ops.conv_mfma(g16, snet.conv_last.packed_dgrad(), mask=acts[-1], mask_slope=0.25, want_raw=True)
+    acts, acts_t, mids = tape.snet["acts"], tape.snet["acts_t"], tape.snet["mids"]
+    _conv_grads(grads, snet.conv_last, acts[-1], g16, reducer=reducer, xt=acts_t[-1])
+    nxt_c = mids[-1].cout if mids else snet.conv1.cout
+    emitting = _side_stream(g16.device) is None
+    dpre, _, dpre_t = _conv3(g16, snet.conv_last.packed_dgrad(), dict(act=None, colsum=nxt_c) if emitting else None, mask=acts[-1], mask_slope=0.25, want_raw=True)
     for k in range(len(mids) - 1, -1, -1):                                       # post-activation stack, DnCNN.py:25-28
-        _conv_grads(grads, mids[k], acts[k], dpre, reducer=reducer)
-        dpre, _ = ops.conv_mfma(dpre, mids[k].packed_dgrad(), mask=acts[k], mask_slope=0.25, want_raw=True)
-    _conv_grads(grads, snet.conv1, tape.snet["rec"], dpre, reducer=reducer)
+        _conv_grads(grads, mids[k], acts[k], dpre, reducer=reducer, xt=acts_t[k], yt=dpre_t)
+        nxt_c = mids[k - 1].cout if k > 0 else snet.conv1.cout
+        dpre, _, dpre_t = _conv3(dpre, mids[k].packed_dgrad(), dict(act=None, colsum=nxt_c) if emitting else None, mask=acts[k], mask_slope=0.25, want_raw=True)
+    _conv_grads(grads, snet.conv1, tape.snet["rec"], dpre, reducer=reducer, yt=dpre_t)
     return grads
 
 
