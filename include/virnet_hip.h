@@ -291,13 +291,16 @@ int virnet_conv_wgrad_f16_s2(const void* hi_t, const void* lo_t, float* dw, floa
  *   act   : T holds lrelu(y, slope) instead of y (the staging transform of the NEXT conv, AttResUNet.py:55, whose weight gradient reads it)
  *   col   : NULL, or virnet_conv_emit_ok()'s nblk * cout floats: partial sums col[(cb * nblk + blk) * 32 + ch] of y over the pixels of
  *           workgroup-wave blk; virnet_colpart_reduce adds them into db (zero db first)
- * virnet_conv_emit_ok: 1 when `d` can run with emission in that form (0: virnet_conv_f16 / virnet_conv_bf16, 1: virnet_conv_wx4). */
+ * virnet_conv_emit_ok: 1 when `d` can run with emission in that form (0: virnet_conv_f16 / virnet_conv_bf16, 1: virnet_conv_wx4 with 16-row
+ * tiles, 2: with 8-row tiles). */
 typedef struct virnet_t_emit {
   void* t_out;
   float* col;
   int act;
   float slope;
   int bf16;
+  int rows;    /* virnet_conv_wx4_emit: 0 / 16 = 16-row tiles (one workgroup per CU), 8 = 8-row tiles (two per CU: the image's stores
+                  run beside the other workgroup's K loop); virnet_conv_emit_ok form 1 / 2 */
 } virnet_t_emit;
 int virnet_conv_emit_ok(const virnet_conv_desc* d, int form, int* nblk);
 int virnet_conv_f16_emit(const virnet_conv_desc* d, const virnet_t_emit* te, int bf16_operands, void* stream);

@@ -40,10 +40,14 @@ CASES = [  # form, n, h, w, c, epi (res, mask), act slope of T, want_act
 ]
 
 
-@pytest.mark.parametrize("form,n,h,w,c,epi,tslope,want_act", CASES)
-def test_emitted_image_is_the_chsplit_of_the_stored_tensor(form, n, h, w, c, epi, tslope, want_act, monkeypatch):
+CASES = [c + (16,) for c in CASES] + [c + (8,) for c in CASES if c[0] == "wx4"]     # the Winograd form emits from 16-row and from 8-row tiles
+
+
+@pytest.mark.parametrize("form,n,h,w,c,epi,tslope,want_act,rows", CASES)
+def test_emitted_image_is_the_chsplit_of_the_stored_tensor(form, n, h, w, c, epi, tslope, want_act, rows, monkeypatch):
     monkeypatch.setenv("VIRNET_CONV_FORM", form)
-    monkeypatch.setenv("VIRNET_WX4_ROWS", "16")                   # (the emitting Winograd form is the 16-row one; pin the reference run to it)
+    monkeypatch.setenv("VIRNET_WX4_ROWS", str(rows))              # (pins the reference run's tile form; the emitting run follows it)
+    monkeypatch.setenv("VIRNET_WX4_EMIT_ROWS", str(rows))
     cp = make_conv(c, c, seed=31).cuda()
     x = nhwc(rnd(n, c, h, w, seed=32))
     res = nhwc(rnd(n, c, h, w, seed=33)) if epi[0] else None

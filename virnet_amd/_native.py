@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
 
 
 class TEmit(C.Structure):
-    _fields_ = [("t_out", C.c_void_p), ("col", C.c_void_p), ("act", C.c_int), ("slope", C.c_float), ("bf16", C.c_int)]
+    _fields_ = [("t_out", C.c_void_p), ("col", C.c_void_p), ("act", C.c_int), ("slope", C.c_float), ("bf16", C.c_int), ("rows", C.c_int)]
 
 
 class PackDesc(C.Structure):

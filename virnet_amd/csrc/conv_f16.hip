@@ -752,10 +752,10 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
   return run(1, 3 * n3 + 2 * n2, n1);
 }
 
-// form 0: conv_f16 / conv_bf16 (8-row tiles, 4 waves); form 1: conv_wx4 (16-row tiles, 8 waves)
+// form 0: conv_f16 / conv_bf16 (8-row tiles, 4 waves); form 1: conv_wx4 (16-row tiles, 8 waves); form 2: conv_wx4, 8-row tiles (4 waves)
 extern "C" int virnet_conv_emit_ok(const virnet_conv_desc* d, int form, int* nblk) {
-  if (!f16_emit_shape_ok(d) || (form != 0 && form != 1)) return 0;
-  if (form == 1 && (d->in_mul || d->cin_pad < 32)) return 0;
+  if (!f16_emit_shape_ok(d) || form < 0 || form > 2) return 0;
+  if (form >= 1 && (d->in_mul || d->cin_pad < 32)) return 0;
   const long th = form == 1 ? 16 : 8, nw = form == 1 ? 8 : 4;
   const long blocks = (long)d->n * ((d->h + th - 1) / th) * ((d->w + 31) / 32) * nw;
   if (blocks >= (1L << 30)) return 0;

@@ -587,7 +587,11 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
           }
           t_units(e8, false, uh[c], ul[c]);
         }
+#ifdef VIRNET_TE_NOSTORE
+        if (trow < a.H && a.t_nseg < 0) {                    // probe build: everything but the T stores
+#else
         if (trow < a.H) {
+#endif
           char* const tq = tb - cq * 64;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -748,7 +752,8 @@ extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) { return
 extern "C" int virnet_conv_wx4_emit(const virnet_conv_desc* d, const virnet_t_emit* te, void* stream) {
   VIRNET_REQUIRE(d != nullptr && te != nullptr && te->t_out != nullptr, "virnet_conv_wx4_emit: NULL descriptor / T buffer");
   int nblk = 0;
-  VIRNET_REQUIRE(virnet_conv_emit_ok(d, 1, &nblk), "virnet_conv_wx4_emit: T emission needs the stride-1 3x3 NHWC conv with ONE stored tensor, no output SFT and no in_mul");
+  VIRNET_REQUIRE(te->rows == 0 || te->rows == 8 || te->rows == 16, "virnet_conv_wx4_emit: rows=%d (0 / 16: 16-row tiles, 8: 8-row tiles)", te->rows);
+  VIRNET_REQUIRE(virnet_conv_emit_ok(d, te->rows == 8 ? 2 : 1, &nblk), "virnet_conv_wx4_emit: T emission needs the stride-1 3x3 NHWC conv with ONE stored tensor, no output SFT and no in_mul");
   VIRNET_REQUIRE(!te->bf16, "virnet_conv_wx4_emit: the Winograd form has split-fp16 operands (T = fp16 hi | lo)");
   VIRNET_REQUIRE(!te->act || (te->slope >= 0.f && te->slope <= 1.f), "virnet_conv_wx4_emit: slope=%g outside [0,1]", te->slope);
   return conv_wx4_impl(d, stream, te);
@@ -837,13 +842,15 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
     const double t8 = 1.04 * (double)full + (tail == 0 ? 0.0 : tail <= n_cu ? 0.55 : 1.04);
     return t8 < t16;
   };
-  if (te) virnet::t_emit_args(k, te, d->w, d->cout, d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * 8);
+  const bool te8 = te && te->rows == 8;                    // emitting form: 16-row tiles (8 waves) or 8-row tiles (4 waves, two workgroups per CU)
+  if (te) virnet::t_emit_args(k, te, d->w, d->cout, te8 ? d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32) * 4 : d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * 8);
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
-    if (te) {                                               // emission: 16-row tiles whatever the launch size
+    if (te8) return virnet::launch_wx4h_emit(kk, nrep, epi, pre, st);
+    if (te) {                                               // emission: the tile form the caller asked for, whatever the launch size
 #define VIRNET_WX4_TE(N_, E_) if (nrep == N_ && epi == E_) return pre == 1 ? launch_wx4<N_, E_, 1, 1>(kk, st) : launch_wx4<N_, E_, 0, 1>(kk, st);
 #define VIRNET_WX4_TEN(N_) VIRNET_WX4_TE(N_, 0) VIRNET_WX4_TE(N_, 1) VIRNET_WX4_TE(N_, 2) VIRNET_WX4_TE(N_, 3)
       VIRNET_WX4_TEN(3) VIRNET_WX4_TEN(2) VIRNET_WX4_TEN(1)

@@ -73,5 +73,6 @@ __device__ __forceinline__ float wx4_coef(int j, int b) {
 
 // launcher of the 8 x 32-pixel form (conv_f16_wx4h.hip); `k` filled as for conv_wx4's own launch
 int launch_wx4h(FArgs k, int nrep, int epi, int pre, hipStream_t st);
+int launch_wx4h_emit(FArgs k, int nrep, int epi, int pre, hipStream_t st);   // TE = 1 instantiations (pre 0 / 1, epi 0..3)
 
 }  // namespace virnet

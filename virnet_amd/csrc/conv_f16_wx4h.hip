@@ -33,8 +33,11 @@ constexpr int WH_VBYTES = 6 * WH_POS;        // 30720
 constexpr int WH_XBLK = 32 * 144 + 64;       // exchange block: [32 columns][32 channels + 16 B pad], skewed by 64 B against its neighbours
 constexpr int WH_CHUNK_BYTES = 36 * 1024;    // one slab's weights of one 16-channel chunk: [6 positions][3 dy][hi|lo][1 KB]
 
-template <int NREP, int EPI, int PRE>
+// TE = 1: T emission (conv_f16_wx4.hip / conv_f16.hip): epilogue items = 8 consecutive pixels of one row, thread = (row of 8, x-segment of 4,
+// channel quad).  With two workgroups per CU the emitted image's stores run beside the other workgroup's K loop.
+template <int NREP, int EPI, int PRE, int TE = 0>
 __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
+  static_assert(!TE || EPI < 4, "T emission: single-store epilogues");
   constexpr int NB = 32 * NREP;
   constexpr int GRP = 4 * NREP * 1024;             // one ring slot: [jt][slab][hi|lo][1 KB]
 
@@ -375,11 +378,12 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   // epilogue reader: thread = (pixel column x of the tile, channel quad cq), items it = rows.  One 32-bit byte offset per item serves
   // the operand loads and the stores (an item outside the image gets an out-of-range offset: loads 0, stores nothing).
   const int cq = tid & 7, px = tid >> 3;
+  const int te_row = tid >> 5, te_xq = (tid >> 3) & 3;       // TE mapping: tile row 0..7, x-segment 0..3 (items = its 8 pixels)
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int oy = oy0 + it, ox = ox0 + px;
+    const int oy = TE ? oy0 + te_row : oy0 + it, ox = TE ? ox0 + te_xq * 8 + it : ox0 + px;
     yoff[it] = (oy < a.H && ox < a.W) ? (unsigned)((oy * a.W + ox) * C + nbase + cq * 4) * 4u : 0x80000000u;
   }
   if constexpr (EPF) op1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((EPI == 1 ? a.res : a.mask) + img_off), 0, a.H * a.W * C * 4, 0x00020000);
@@ -421,7 +425,17 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   const int r_q = (3 + (pk & 1)) * WH_XBLK + pxt * 144 + cq * 16;
   const int r_e = 5 * WH_XBLK + pxt * 144 + cq * 16;
   const float ck = (float)(1 << pk), ek = pk == 3 ? 1.f : 0.f;
+  const int te_base = (te_row >> 2) * 6 * WH_XBLK + ((te_row & 3) * 8) * 144 + cq * 16;
   auto xread = [&](int it) {                                // row it: row block it>>2, row-in-block it&3
+    if constexpr (TE) {                                     // pixel te_xq*8 + it of row te_row: x-tile te_xq*2 + (it>>2), pixel-in-tile it&3
+      const int pkk = it & 3;
+      const int b0 = te_base + (te_xq * 2 + (it >> 2)) * 144;
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xb + b0 + ((pkk == 0) ? 0 : (pkk == 2) ? 2 : 1) * WH_XBLK);
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + b0 + (3 + (pkk & 1)) * WH_XBLK);
+      f32x4 r = p + (float)(1 << pkk) * qv;
+      if (pkk == 3) r += *reinterpret_cast<const f32x4*>(xb + b0 + 5 * WH_XBLK);
+      return r;
+    }
     const int base = (it >> 2) * 6 * WH_XBLK + ((it & 3) * 8) * 144;
     const f32x4 p = *reinterpret_cast<const f32x4*>(xb + base + r_p);
     const f32x4 qv = *reinterpret_cast<const f32x4*>(xb + base + r_q);
@@ -481,6 +495,40 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+      if constexpr (TE) {
+        const int trow = oy0 + te_row;
+        const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
+        char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + te_xq + 1)) * 512 + cq * 64;
+        f32x4 cs = zero4;
+        u32x4 uh[4], ul[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float e8[8];
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const float sv = yoff[it] != 0x80000000u ? tv[it][c] : 0.f;      // (tile pixels beyond the image are zero in T)
+            cs[c] += sv;
+            e8[it] = a.t_act ? fmaxf(sv, sv * a.t_slope) : sv;
+          }
+          t_units(e8, false, uh[c], ul[c]);
+        }
+        if (trow < a.H) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(tb + i * 16) = uh[i];
+            *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + i * 16) = ul[i];
+          }
+        }
+        if (a.t_col) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            cs[c] += __shfl_xor(cs[c], 8);
+            cs[c] += __shfl_xor(cs[c], 16);
+            cs[c] += __shfl_xor(cs[c], 32);
+          }
+          if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 4 + wave) * 32 + cq * 4) = cs;
+        }
+      }
       if (nr == 0) TSTAMP(7);
       if (nr + 1 < NREP) wx_lds_barrier();
     }
@@ -518,14 +566,14 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   TSTAMP(3);
 }
 
-template <int NREP, int EPI, int PRE>
+template <int NREP, int EPI, int PRE, int TE = 0>
 int launch_wx4h_t(FArgs k, hipStream_t st) {
   constexpr int LDS_K = WH_VBYTES + 4 * 4 * NREP * 1024;
   constexpr int LDS_E = 12 * WH_XBLK;
   constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 2 * 32 * NREP * 4;      // + the channel block's inverse scales and biases
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
   static unsigned long long attr_done = 0;
-  auto kern = conv_wx4h_kernel<NREP, EPI, PRE>;
+  auto kern = conv_wx4h_kernel<NREP, EPI, PRE, TE>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_wx4h): %s", hipGetErrorString(e));
@@ -550,6 +598,15 @@ int launch_wx4h_t(FArgs k, hipStream_t st) {
 }  // namespace
 
 namespace virnet {
+
+int launch_wx4h_emit(FArgs k, int nrep, int epi, int pre, hipStream_t st) {
+#define VIRNET_WX4H_TE(N_, E_) if (nrep == N_ && epi == E_) return pre == 1 ? launch_wx4h_t<N_, E_, 1, 1>(k, st) : launch_wx4h_t<N_, E_, 0, 1>(k, st);
+#define VIRNET_WX4H_TEN(N_) VIRNET_WX4H_TE(N_, 0) VIRNET_WX4H_TE(N_, 1) VIRNET_WX4H_TE(N_, 2) VIRNET_WX4H_TE(N_, 3)
+  VIRNET_WX4H_TEN(3) VIRNET_WX4H_TEN(2) VIRNET_WX4H_TEN(1)
+#undef VIRNET_WX4H_TEN
+#undef VIRNET_WX4H_TE
+  return virnet::set_error("virnet_conv_wx4_emit (8-row tiles): no emitting kernel for nrep=%d epi=%d pre=%d", nrep, epi, pre);
+}
 
 int launch_wx4h(FArgs k, int nrep, int epi, int pre, hipStream_t st) {
 #define VIRNET_WX4H_EPI(N_, E_)                                                                                               \

@@ -105,7 +105,7 @@ DEFAULT_CONV_FORM = "wx4"
 
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
-_KNOBS = ("VIRNET_T_EMIT", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
+_KNOBS = ("VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
           "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
@@ -523,8 +523,12 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
     timg = None
     nblk = C.c_int(0)
     lib = nat.load()
+    rows = 0
+    if form == "wx4":                                    # emitting tile form of the Winograd kernel: VIRNET_WX4_EMIT_ROWS = 8 | 16
+        rows = 8 if _env("VIRNET_WX4_EMIT_ROWS", "8") == "8" and _env("VIRNET_DETERMINISTIC", "0") != "1" and _env("VIRNET_WX4_MIN_WGS") != "0" \
+            and _env("VIRNET_WX4_ROWS") != "16" else 16
     if (t_emission_enabled() and form in ("f16x3", "bf16", "wx4") and not pw.transposed and stride == 1
-            and lib.virnet_conv_emit_ok(C.byref(d), int(form == "wx4"), C.byref(nblk))):
+            and lib.virnet_conv_emit_ok(C.byref(d), (2 if rows == 8 else 1) if form == "wx4" else 0, C.byref(nblk))):
         timg = t_acquire(n, oh, ow, cstore, form == "bf16", x.device)
         col = None
         ncol = emit.get("colsum")
@@ -533,7 +537,7 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
             timg.db = torch.zeros(ncol, dtype=torch.float32, device=x.device)
         slope_t = emit.get("act")
         te = nat.TEmit(t_out=nat.ptr(timg.buf), col=nat.ptr(col), act=int(slope_t is not None), slope=0.0 if slope_t is None else slope_t,
-                       bf16=int(form == "bf16"))
+                       bf16=int(form == "bf16"), rows=rows)
         _launch_conv(d, flops, what + "(+T)", form, te)
         if col is not None:
             nat.check(lib.virnet_colpart_reduce(nat.ptr(col), nat.ptr(timg.db), nblk.value, cstore // 32, ncol, nat.stream_handle()), "colpart_reduce")
