@@ -446,6 +446,11 @@ def t_release(t: Optional[TImage]) -> None:
         t.buf = None
 
 
+def t_pool_clear() -> None:
+    """Drop the recycled T buffers (they are grow-only: one set per geometry the training step has seen)."""
+    _T_POOL.clear()
+
+
 def t_emission_enabled() -> bool:
     """VIRNET_T_EMIT=0 keeps the separate re-layout passes (A/B runs)."""
     return _env("VIRNET_T_EMIT", "1") != "0"
