@@ -844,11 +844,14 @@ def conv_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], *, stride: 
     if (not transposed and stride == 1 and ks == 3 and h >= 5 and form in ("f16x3", "bf16", "wx4")
             and _env("VIRNET_WGRAD_FORM", "f16") != "f32"):
         dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)      # every element is written by the reduction
-        return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
-                               bias_channels=bias_channels, xt=xt, yt=yt)
+        # bf16 form: the C->C layers contract bf16-rounded operands; a few-channel layer (tail, head, conv_last, SNet conv1) stays
+        # fp32-class unless its big operand already exists as an emitted bf16 image -- then it takes that image instead of re-laying
+        # the tensor (its other operand is a 16-channel record)
+        bf = form == "bf16" and (min(cin, cout) >= 32 or (xt is not None and xt.bf16) or (yt is not None and yt.bf16))
+        return _conv_wgrad_f16(x, dy, dw, cin, cout, in_slope, in_mul, in_add, bf16=bf, bias_channels=bias_channels, xt=xt, yt=yt)
     if not transposed and stride == 2 and ks == 3 and _wgrad_s2_ok(h // 2, cx):
         return _conv_wgrad_f16_s2(x, dy, weight_shape, 0, in_slope, in_mul, in_add, bf16=(form == "bf16" and min(cin, cout) >= 32),
-                                  bias_channels=bias_channels)
+                                  bias_channels=bias_channels, lo_t=yt)
     dw = torch.zeros(weight_shape, dtype=torch.float32, device=x.device)
     rows = 4 * cout if transposed else cout
     ctr = torch.zeros(((rows + 31) // 32) * ((cin + 31) // 32), dtype=torch.int32, device=x.device)
@@ -885,7 +888,7 @@ def _wgrad_s2_ok(oh: int, chi: int) -> bool:
     return (conv_form() in ("f16x3", "bf16", "wx4") and _env("VIRNET_WGRAD_FORM", "f16") != "f32" and oh >= 5 and chi % 32 == 0)
 
 
-def convt_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...]):
+def convt_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...], xt: Optional[TImage] = None):
     """(dw [cin][cout][2][2], db [cout]) of ConvTranspose2d(k=2, s=2) (UpBlock.upsampler, AttResUNet.py:80) from its NHWC input ``x``
     [n,h,w,cx] and the NHWC gradient of its output ``dy`` [n,2h,2w,cout]: on the f16 pipe (the bias gradient rides on the re-layout pass
     over ``dy``), or -- fp32 forms, tiny maps -- the fp32 kernel on the space-to-depth gradient plus a column sum."""
@@ -896,7 +899,7 @@ def convt_wgrad(x: Tensor, dy: Tensor, weight_shape: Tuple[int, ...]):
         raise ValueError(f"dy shape {tuple(dy.shape)} != {(n, 2 * h, 2 * w, cout)}")
     if _wgrad_s2_ok(h, cout):
         return _conv_wgrad_f16_s2(dy, x, weight_shape, 1, None, None, None, bf16=(conv_form() == "bf16" and min(cin, cout) >= 32),
-                                  bias_channels=cout)
+                                  bias_channels=cout, lo_t=xt)
     return conv_wgrad(x, space_to_depth2(dy), weight_shape, transposed=True), colsum(dy)
 
 
@@ -963,7 +966,7 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
 
 
 def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope, in_mul, in_add, *, bf16: bool,
-                       bias_channels: Optional[int] = None):
+                       bias_channels: Optional[int] = None, lo_t: Optional[TImage] = None):
     """Weight gradient of a stride-2 layer on the f16 pipe.  ``hi`` = the high-resolution operand [n,2oh,2ow,chi], re-laid as a
     column-phase T (``virnet_chsplit_s2``); ``lo`` = the low-resolution one [n,oh,ow,clo] (plain T).  mode 0: 3x3 stride-2 conv (hi = its
     input, with the staging transform; lo = dY, whose pass yields the bias gradient); mode 1: 2x2 transposed conv (hi = dY: bias
@@ -974,8 +977,13 @@ def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope
     if (hh, hw) != (2 * oh, 2 * ow):
         raise ValueError(f"stride-2 weight gradient: {tuple(hi.shape)} is not twice {tuple(lo.shape)}")
     st = nat.stream_handle()
+    # the low-resolution operand as an image a convolution already emitted (plain layout): usable when it is exactly the image this call
+    # would build -- for the stride-2 conv it must bring the channel sums (its dY's bias gradient) along
+    if lo_t is not None and ((lo_t.n, lo_t.h, lo_t.w, lo_t.c) != (n, oh, ow, clo) or lo_t.bf16 != bf16 or lo_t.buf is None
+                             or (mode == 0 and bias_channels is not None and (lo_t.db is None or lo_t.db.numel() != bias_channels))):
+        lo_t = None
     ht = _workspace("wgrad_xt", lib.virnet_chsplit_s2_bytes(n, hh, hw, chi), hi.device)
-    lt = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, oh, ow, clo), hi.device)
+    lt = lo_t.buf if lo_t is not None else _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, oh, ow, clo), hi.device)
     timed = _TIMER is not None
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -986,14 +994,17 @@ def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope
         db = torch.zeros(bias_channels, dtype=torch.float32, device=hi.device)
         if mode == 1:
             hcol = _workspace("wgrad_col", lib.virnet_chsplit_s2_colsum_bytes(n, hh, hw, chi), hi.device)
+        elif lo_t is not None:
+            db = lo_t.db
         else:
             lcol = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, oh, ow, clo), hi.device)
     bc = 0 if bias_channels is None else bias_channels
     nat.check(lib.virnet_chsplit_s2(nat.ptr(hi), n, hh, hw, chi, int(in_slope is not None), 0.0 if in_slope is None else in_slope,
                                     nat.ptr(in_mul), nat.ptr(in_add), int(bf16), nat.ptr(ht), nat.ptr(hcol), nat.ptr(db) if hcol is not None else None,
                                     bc if hcol is not None else 0, st), "chsplit_s2")
-    nat.check(lib.virnet_chsplit(nat.ptr(lo), n, oh, ow, clo, 0, 0.0, None, None, int(bf16), nat.ptr(lt), nat.ptr(lcol),
-                                 nat.ptr(db) if lcol is not None else None, bc if lcol is not None else 0, st), "chsplit")
+    if lo_t is None:
+        nat.check(lib.virnet_chsplit(nat.ptr(lo), n, oh, ow, clo, 0, 0.0, None, None, int(bf16), nat.ptr(lt), nat.ptr(lcol),
+                                     nat.ptr(db) if lcol is not None else None, bc if lcol is not None else 0, st), "chsplit")
     if mode == 0:
         cout, cin = weight_shape[0], weight_shape[1]
     else:

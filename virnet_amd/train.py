@@ -93,9 +93,11 @@ def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
         order.append(("block", blk, xin, (f1a, xin_t, f1a_t)))
         return out, out_t
 
+    nlev = len(down_levels)
     for ii, body in enumerate(down_levels):
         for bi, blk in enumerate(body):
-            xcur, xcur_t = block(blk, xcur, xcur_t, ACT02 if bi + 1 < len(body) else None)
+            # (the bottom level's last block feeds the first transposed conv: its weight gradient takes the plain image as low-res operand)
+            xcur, xcur_t = block(blk, xcur, xcur_t, ACT02 if bi + 1 < len(body) else (PLAIN if ii + 1 == nlev and rnet.up_path else None))
         if ii + 1 < len(rnet.down_path):
             bridges.append(xcur)
             out, _ = ops.conv_mfma(xcur, rnet.down_path[ii].downsampler.packed(), stride=2, want_raw=True)
@@ -103,12 +105,12 @@ def denoise_forward_train(net, x: Tensor) -> Tuple[Tensor, Tensor, _Tape]:
             xcur, xcur_t = out, None
     for jj, up in enumerate(rnet.up_path):
         out, _ = ops.conv_mfma(xcur, up.upsampler.packed(), res=bridges[-jj - 1], want_raw=True)
-        order.append(("up", up.upsampler, xcur, len(bridges) - 1 - jj))
+        order.append(("up", up.upsampler, xcur, (len(bridges) - 1 - jj, xcur_t)))
         xcur, xcur_t = out, None
         body = up_levels[jj]
         for bi, blk in enumerate(body):
             last = bi + 1 == len(body)
-            xcur, xcur_t = block(blk, xcur, xcur_t, (PLAIN if jj + 1 == len(rnet.up_path) else None) if last else ACT02)
+            xcur, xcur_t = block(blk, xcur, xcur_t, PLAIN if last else ACT02)      # (last: the next transposed conv or the tail take the plain image)
     mu = _thin(rnet.tail, xcur, (h, w), op=nat.NCHW_ADD, res=x)
     tape.misc = dict(rec=rec, x_last=xcur, x_last_t=xcur_t, order=order, nbridges=len(bridges), hw=(h, w), hpwp=(hp, wp), cond=cond)
     return mu, sigma, tape
@@ -135,7 +137,7 @@ def _side_stream(device: torch.device) -> Optional["torch.cuda.Stream"]:
 def _wgrad_pair(conv, x_in: Tensor, dy: Tensor, stride: int, in_slope: Optional[float], cvalid: Optional[int], xt=None, yt=None) -> Dict:
     """{weight: dW[, bias: db]} of one conv; the bias gradient rides on the weight-gradient's pass over dy where it can.
     ``xt`` / ``yt``: operand images a conv's epilogue already emitted (ops.TImage), returned to the pool here."""
-    kw = dict(xt=xt, yt=yt) if (stride == 1 and (xt is not None or yt is not None)) else {}
+    kw = dict(xt=xt, yt=yt) if (stride == 1 and (xt is not None or yt is not None)) else (dict(yt=yt) if stride == 2 and yt is not None else {})
     try:
         if conv.bias is None:
             return {conv.weight: ops.conv_wgrad(x_in, dy, tuple(conv.weight.shape), stride=stride, in_slope=in_slope, **kw)}
@@ -210,7 +212,9 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
         def emit_for(idx):          # the consumer of the gradient that flows INTO order[idx] (None: no stride-1 weight gradient takes it as dY)
             if idx < 0:
                 return dy_spec(rnet.head.cout)                                  # the head's weight gradient
-            return dy_spec(order[idx][1].conv2.cout) if order[idx][0] == "block" else None   # (stride-2 / transposed: other layouts)
+            if order[idx][0] == "block":
+                return dy_spec(order[idx][1].conv2.cout)
+            return dy_spec(order[idx][1].cout) if order[idx][0] == "down" else None     # (stride-2 conv: its low-res operand; transposed: column-phase layout)
 
         last = len(order) - 1
         dx, _, dx_t = _conv3(g16, rnet.tail.packed_dgrad(), emit_for(last), want_raw=True)
@@ -227,13 +231,15 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
                 dx, _, dx_t = _conv3(d_f1, mod.conv1.packed_dgrad(), nxt, mask=x_in, mask_slope=0.2, res=dx, want_raw=True)
             elif kind == "up":                                                  # UpBlock.upsampler + bridge, AttResUNet.py:84-87
                 ops.t_release(dx_t); dx_t = None
+                aux, xin_t = aux
                 dbridge[aux] = dx
                 side = _side_stream(dx.device)
                 main = torch.cuda.current_stream(dx.device)
                 if side is not None:
                     side.wait_stream(main)
                 with torch.cuda.stream(side if side is not None else main):        # same stream as every other push (bucket order)
-                    dw, db = ops.convt_wgrad(x_in, dx, tuple(mod.weight.shape))
+                    dw, db = ops.convt_wgrad(x_in, dx, tuple(mod.weight.shape), xt=xin_t)
+                    ops.t_release(xin_t)
                     new = {mod.weight: dw, mod.bias: db}
                     if reducer is not None:
                         reducer.push(new)
@@ -245,8 +251,8 @@ def denoise_backward(net, tape: _Tape, dmu: Optional[Tensor], dsigma: Optional[T
                 grads.update(new)
                 dx = ops.convt_dgrad(dx, mod.packed_dgrad())                    # (the stride-2 kernel does not emit: the next block re-lays this one)
             else:                                                               # DownBlock.downsampler, AttResUNet.py:67,74
-                ops.t_release(dx_t); dx_t = None                                # (its weight gradient takes the column-phase layout)
-                _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer)
+                _conv_grads(grads, mod, x_in, dx, stride=2, reducer=reducer, yt=dx_t)   # (dx_t: its low-resolution operand + bias sums)
+                dx_t = None
                 nb -= 1
                 dx, _, dx_t = _conv3(ops.zero_stuff2(dx), mod.packed_dgrad(), nxt, res=dbridge[nb], want_raw=True)
         # ---- head (AttResUNet.py:153-155): weights, and the gradient flowing into sqrt(sigma) through the conditioning channel
