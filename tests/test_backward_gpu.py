@@ -445,3 +445,53 @@ def test_train_step_config4_as_written_bf16_full_size(monkeypatch):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("form", ["wx4", "bf16"])
+def test_training_step_with_and_without_T_emission_agree(form, monkeypatch):
+    """The convolutions of the step emit the weight-gradient GEMM's operand images from their epilogues (csrc TE = 1 kernels); VIRNET_T_EMIT=0
+    re-lays every operand with virnet_chsplit instead.  The emitted image is bit for bit the re-laid one, so every WEIGHT gradient must be
+    bitwise identical between the two runs (ragged 52 x 76 images: tiles that overhang the image on both axes, Winograd form on level 0);
+    bias gradients are sums in a different order (per-workgroup partial sums): fp32 noise."""
+    from virnet_amd.networks import VIRAttResUNet
+    from virnet_amd.utils.synth import synth_images, synth_state_dict
+    monkeypatch.setenv("VIRNET_CONV_FORM", form)
+    cfg = dict(im_chn=3, sigma_chn=1, n_feat=[96, 192, 288], dep_S=5, n_resblocks=2, noise_cond=True, extra_mode="Input")
+    net = VIRAttResUNet(**cfg)
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, seed=5))
+    net = net.cuda().train()
+    n, h, w = 12, 52, 76
+    gt = synth_images(n, 3, h, w, seed=1).cuda()
+    sig_gt = (0.02 + 0.25 * synth_images(n, 1, h, w, seed=2).cuda()) ** 2
+    noisy = gt + (synth_images(n, 3, h, w, seed=3).cuda() - 0.5) * 0.4
+
+    def step():
+        for p in net.parameters():
+            p.grad = None
+        mu, sigma = net(noisy)
+        _elbo(mu, sigma, noisy, gt, sig_gt, eps2=1e-2).backward()
+        return mu.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}
+
+    mu_a, g_a = step()
+    monkeypatch.setenv("VIRNET_T_EMIT", "0")
+    mu_b, g_b = step()
+    # (the forward may pick another tile form for the emitting launches: same arithmetic class, not the same bits -- compare gradients
+    #  only where the forms coincide, i.e. under the pinned form below; here: fp32 noise)
+    assert float((mu_a - mu_b).abs().max()) <= 2e-5 * max(1.0, float(mu_b.abs().max()))
+    for k in g_a:
+        scale = max(float(g_b[k].abs().max()), 1e-12)
+        assert float((g_a[k] - g_b[k]).abs().max()) <= (2e-2 if form == "bf16" else 1e-4) * scale, k
+    # pinned kernel form and tile height: emission changes no weight-gradient bit
+    monkeypatch.setenv("VIRNET_DETERMINISTIC", "1")
+    _, g_d0 = step()                                     # VIRNET_T_EMIT=0
+    monkeypatch.delenv("VIRNET_T_EMIT")
+    _, g_d1 = step()
+    thin = ("SNet.conv1.weight", "SNet.conv_last.weight", "RNet.head.weight", "RNet.tail.weight")
+    for k in g_d0:
+        if form == "bf16" and k in thin:
+            # (bf16 form: a few-channel layer takes the emitted bf16 image of its big operand; without emission it re-lays it in split fp16)
+            assert float((g_d0[k] - g_d1[k]).abs().max()) <= 2e-2 * max(float(g_d0[k].abs().max()), 1e-12), k
+        elif k.endswith(".weight"):
+            assert torch.equal(g_d0[k], g_d1[k]), k
+        else:
+            assert float((g_d0[k] - g_d1[k]).abs().max()) <= 2e-5 * max(float(g_d0[k].abs().max()), 1e-12), k
