@@ -229,6 +229,10 @@ typedef struct virnet_pack_desc {
   int zero_pad;      /* 1: positions beyond h*sf, w*sf are zero instead of reflected (gradient records of the training step) */
 } virnet_pack_desc;
 int virnet_pack_input(const virnet_pack_desc* d, void* stream);
+/* The same entry folded into the first convolution (AttResUNet.head AttResUNet.py:153-155, DnCNN.conv1 DnCNN.py:38): virnet_conv_f16 on
+ * ONE 16-channel chunk (d->cin_pad = 16, d->h x d->w = e->hp x e->wp, plain single-store epilogue) whose staging gathers each pixel's
+ * record [image | vector | map | 0] from the NCHW sources of `e` -- the packed tensor never exists (e->out is ignored; c0 + ev + em <= 8). */
+int virnet_conv_f16_entry(const virnet_conv_desc* d, const virnet_pack_desc* e, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step: weight / bias gradients and the layout helpers of the input-gradient convs.

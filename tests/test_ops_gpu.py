@@ -446,3 +446,54 @@ def test_winograd_randomised_sweep_against_direct_kernel(monkeypatch):
                     worst = max(worst, e)
                     assert e <= 5e-5, (case, form, cin, cout, n, h, w, opts, e)
     assert worst > 0.0            # the two algorithms are different roundings of the same sums
+
+
+@pytest.mark.parametrize("n,c0,h,w,sf,hp,wp,ev,em,msf,msqrt,cout,act", [
+    (2, 3, 45, 70, 1, 48, 72, 0, 1, 1, True, 96, False),      # denoiser head: image + sqrt(sigma) map, reflect pad on both axes
+    (1, 3, 64, 64, 1, 64, 64, 0, 0, 1, False, 64, True),      # DnCNN.conv1: image only, activated store
+    (3, 3, 16, 20, 4, 64, 80, 4, 0, 1, False, 96, False),     # SISR head: nearest x4, kernel / noise vector
+    (2, 3, 9, 7, 3, 28, 24, 3, 1, 3, True, 96, False),        # SISR with a per-pixel variance map (nearest x3) + vector, padded
+    (5, 1, 33, 31, 2, 68, 64, 0, 2, 2, False, 32, True),      # one image channel, two map channels
+])
+def test_conv_entry_is_bitwise_pack_plus_conv(n, c0, h, w, sf, hp, wp, ev, em, msf, msqrt, cout, act, monkeypatch):
+    """virnet_conv_f16_entry (the entry packing folded into the first conv's staging) against virnet_pack_input + virnet_conv_f16: the
+    same values are staged, so the result is bit for bit the two-launch one (util_net.py:20-25 reflect pad, VIRNet.py:83,94 nearest
+    up-sampling, VIRNet.py:44 sqrt, AttResUNet.py:153 concat)."""
+    cp = make_conv(c0 + ev + em, cout, seed=61).cuda()
+    x = rnd(n, c0, h, w, seed=62, lo=0.0, hi=1.0).cuda()
+    vec = rnd(n, ev, seed=63).cuda() if ev else None
+    mp = rnd(n, em, h * sf // msf, w * sf // msf, seed=64, lo=0.01, hi=2.0).cuda() if em else None
+    kw = dict(sf=sf, vec=vec, map_=mp, map_sf=msf, map_sqrt=msqrt, want_act=act, slope=0.25)
+    fused = ops.conv_entry(x, cp.packed(), hp, wp, **kw)
+    monkeypatch.setenv("VIRNET_ENTRY_FUSED", "0")
+    two = ops.conv_entry(x, cp.packed(), hp, wp, **kw)
+    rec = ops.pack_input(x, hp, wp, sf=sf, vec=vec, map_=mp, map_sf=msf, map_sqrt=msqrt)
+    raw, a2 = ops.conv_mfma(rec, cp.packed(), want_raw=not act, want_act=act, slope=0.25)
+    assert torch.equal(two, a2 if act else raw)
+    assert tuple(fused.shape) == (n, hp, wp, cout) and torch.equal(fused, two)
+
+
+def test_conv_entry_abi_rejects_bad_descriptors():
+    lib = nat.load()
+    cp = make_conv(3, 64).cuda()
+    pw = cp.packed()
+    x = torch.zeros(1, 3, 8, 8, device="cuda")
+    y = torch.empty(1, 8, 8, 64, device="cuda")
+    import ctypes as C
+    def desc(**over):
+        kw = dict(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=nat.ptr(pw.bias), res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0,
+                  y_raw=nat.ptr(y), y_act=0, n=1, h=8, w=8, cin_pad=16, cout=64, n_pad=64, nrep=pw.nrep, ks=3, stride=1, epi=nat.EPI_NHWC,
+                  nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=0, in_slope=0.0, slope=0.2, clamp_lo=0.0, clamp_hi=0.0)
+        kw.update(over)
+        return nat.ConvDesc(**kw)
+    def ent(**over):
+        kw = dict(x=nat.ptr(x), vec=0, map=0, out=0, n=1, c0=3, h=8, w=8, sf=1, ev=0, em=0, mh=0, mw=0, msf=1, map_sqrt=0, hp=8, wp=8, zero_pad=0)
+        kw.update(over)
+        return nat.PackDesc(**kw)
+    st = nat.stream_handle()
+    assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent()), st) == 0
+    assert lib.virnet_conv_f16_entry(C.byref(desc(res=nat.ptr(y))), C.byref(ent()), st) != 0          # residual: not an entry
+    assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent(hp=12)), st) != 0                   # geometry mismatch
+    assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent(c0=6, ev=3)), st) != 0              # more than 8 record channels
+    assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent(ev=2)), st) != 0                    # vector channels without a vector
+    torch.cuda.synchronize()

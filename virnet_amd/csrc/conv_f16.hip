@@ -44,9 +44,12 @@ using namespace virnet;
 // over (FArgs::t_out; wgrad_f16.hip's T) and the tile's channel sums -- what a virnet_chsplit pass over the stored tensor would produce,
 // without reading it back.  The reader's items become 8 CONSECUTIVE pixels (one 16-byte T unit per channel and plane) instead of 8
 // pixels eight apart; the NHWC stores cover 128 contiguous bytes per 8 lanes either way.
-template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0>
+// ENT = 1: the network entries (AttResUNet.head :153-155, DnCNN.conv1 :38): ONE 16-channel chunk whose pixels are gathered from the NCHW
+// image (+ conditioning vector / map) while they are staged -- virnet_pack_input's record never exists in HBM (FArgs::ent).
+template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0, int ENT = 0>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   static_assert(!TE || (MREP == 2 && EPI < 4), "T emission: 8-row tiles (8 items per thread), single-store epilogues");
+  static_assert(!ENT || (EPI == 0 && !BF && !TE), "entry form: plain single-store epilogue, split-fp16 operands");
   constexpr int TH = 4 * MREP, IH = TH + 2, IW = 34, NPIX = IH * IW;
   constexpr int NPIECE = NPIX * 2;                 // (pixel, 8-channel half) staging pieces of one chunk
   constexpr int PPT = (NPIECE + 255) / 256;
@@ -87,6 +90,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   unsigned soff[PPT];
   int sdst[PPT];
   bool sinb[PPT];
+  [[maybe_unused]] int egy[PPT], egx[PPT];             // ENT: clamped pixel coordinates of the piece
+  [[maybe_unused]] bool ehalf[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int qq = k * 256 + tid;
@@ -96,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     const int gy = iy0 + iy, gx = ix0 + ix;
     sinb[k] = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     const int gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+    egy[k] = gyc; egx[k] = gxc; ehalf[k] = h != 0;
     soff[k] = (unsigned)((gyc * a.W + gxc) * a.Cin + h * 8);
     sdst[k] = p * 32 + ((h ^ ((p >> 3) & 1)) << 4);
   }
@@ -168,8 +174,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   f32x4 pr0[PPT], pr1[PPT];
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
-    pr0[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k]);
-    pr1[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k] + 4);
+    if constexpr (ENT) {
+      pr0[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      pr1[k] = pr0[k];
+      if (!ehalf[k]) entry_pixel(a.ent, img, egy[k], egx[k], pr0[k], pr1[k]);      // (channels 8..15 of an entry record are zero)
+    } else {
+      pr0[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k]);
+      pr1[k] = *reinterpret_cast<const f32x4*>(ximg + soff[k] + 4);
+    }
   }
 #pragma unroll
   for (int k = 0; k < PPT; ++k) stage_store(x_lds, 0, k, pr0[k], pr1[k]);
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     // one piece of the next chunk's pixels (the last chunk re-stages itself into the idle buffer: no branch in the tap code)
     const int cn = min(c + 1, nch - 1);
     f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    if constexpr (g < PPT) {
+    if constexpr (g < PPT && !ENT) {                   // (entry form: one chunk, gathered in the prologue; nothing to re-stage)
       const float* const src = ximg + soff[g] + cn * 16;
       s0 = *reinterpret_cast<const f32x4*>(src);
       s1 = *reinterpret_cast<const f32x4*>(src + 4);
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #pragma unroll
           for (int r = 0; r < MREP; ++r) read_b(xb, r, g + 1);
         }
-        if constexpr (g < PPT) stage_store(xn, cn, g, s0, s1);
+        if constexpr (g < PPT && !ENT) stage_store(xn, cn, g, s0, s1);
       }
 #pragma unroll
       for (int part = BF ? 2 : 0; part < 3; ++part)
@@ -504,14 +516,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 #endif
 }
 
-template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0>
+template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0, int ENT = 0>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
   constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);       // K loop: pixel tiles + weight stages
   constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144 + (TE ? 128 : 0));   // epilogue: two turn-around regions per wave
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static unsigned long long attr_done = 0;
-  auto kern = conv_f16_kernel<MREP, NREP, EPI, BF, TE>;
+  auto kern = conv_f16_kernel<MREP, NREP, EPI, BF, TE, ENT>;
   if (virnet::first_use_on_device(attr_done)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_f16): %s", hipGetErrorString(e));
@@ -604,7 +616,7 @@ extern "C" int virnet_pack_bf16_weight(const float* w, int dgrad, int cout, int 
   return virnet::check_launch("pack_bf16 launch");
 }
 
-static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te = nullptr);
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te = nullptr, const virnet_pack_desc* ent = nullptr);
 
 extern "C" int virnet_conv_f16(const virnet_conv_desc* d, void* stream) { return conv_f16_impl(d, stream, 0); }
 
@@ -629,7 +641,24 @@ extern "C" int virnet_conv_bf16(const virnet_conv_desc* d, void* stream) {
   return conv_f16_impl(d, stream, 1);
 }
 
-static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te) {
+extern "C" int virnet_conv_f16_entry(const virnet_conv_desc* d, const virnet_pack_desc* e, void* stream) {
+  VIRNET_REQUIRE(d != nullptr && e != nullptr && e->x != nullptr, "virnet_conv_f16_entry: NULL descriptor / image");
+  VIRNET_REQUIRE(d->ks == 3 && d->stride == 1 && d->epi == VIRNET_EPI_NHWC && d->cin_pad == 16, "virnet_conv_f16_entry: the stride-1 3x3 NHWC conv on ONE 16-channel chunk (cin_pad=%d)", d->cin_pad);
+  VIRNET_REQUIRE(!d->res && !d->mask && !d->mul && !d->in_mul && !d->in_act && ((d->y_raw != nullptr) != (d->y_act != nullptr)),
+                 "virnet_conv_f16_entry: plain single-store epilogue only (no residual / mask / SFT / input activation)");
+  VIRNET_REQUIRE(e->n == d->n && e->hp == d->h && e->wp == d->w, "virnet_conv_f16_entry: the entry %d x %dx%d does not match the conv input %d x %dx%d",
+                 e->n, e->hp, e->wp, d->n, d->h, d->w);
+  VIRNET_REQUIRE(e->c0 >= 1 && e->ev >= 0 && e->em >= 0 && e->c0 + e->ev + e->em <= 8, "virnet_conv_f16_entry: %d+%d+%d channels (the fused entry holds 8)", e->c0, e->ev, e->em);
+  VIRNET_REQUIRE(e->h > 0 && e->w > 0 && e->sf >= 1 && e->hp >= e->h * e->sf && e->wp >= e->w * e->sf && e->hp - e->h * e->sf < e->h * e->sf && e->wp - e->w * e->sf < e->w * e->sf,
+                 "virnet_conv_f16_entry: bad geometry %dx%d x%d -> %dx%d (reflect pad must stay below the image size)", e->h, e->w, e->sf, e->hp, e->wp);
+  VIRNET_REQUIRE(e->ev == 0 || e->vec, "virnet_conv_f16_entry: ev=%d without vec", e->ev);
+  VIRNET_REQUIRE(e->em == 0 || (e->map && e->msf >= 1), "virnet_conv_f16_entry: em=%d without map/msf", e->em);
+  virnet_conv_desc dd = *d;
+  dd.x = e->x;                                             // (never dereferenced as NHWC: the staging gathers through `ent`)
+  return conv_f16_impl(&dd, stream, 0, nullptr, e);
+}
+
+static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const virnet_t_emit* te, const virnet_pack_desc* ent) {
   VIRNET_REQUIRE(d != nullptr, "virnet_conv_f16: desc is NULL");
   VIRNET_REQUIRE(d->x && d->wpack, "virnet_conv_f16: x / wpack is NULL");
   if (d->ks == 1 && d->epi == VIRNET_EPI_CONVT) {                // UpBlock.upsampler + bridge (AttResUNet.py:80,84-87): conv_f16_pw.hip
@@ -712,6 +741,7 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
     if (nb > 1 && tiles4 * (n3 + n2 + n1) <= split_below && !te) { n3 = 0; n2 = 0; n1 = nb; }
   }
   if (te) virnet::t_emit_args(k, te, d->w, d->cout, (int)(tiles8 * 4));      // (emission runs on 8-row tiles whatever the grid: 4 waves per tile)
+  if (ent) { k.ent = *ent; k.ent.out = nullptr; }
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
@@ -719,6 +749,12 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
     kk.NP = groups * nrep * 32;
     int mrep = (tiles8 * groups >= 1024) ? 2 : 1;
     if (forced_m == 1 || forced_m == 2) mrep = forced_m;
+    if (ent) {
+      if (epi != 0 || bf) return virnet::set_error("virnet_conv_f16_entry: epilogue %d / bf16 operands have no entry form", epi);
+#define VIRNET_F16_ENT(M_, N_) if (mrep == M_ && nrep == N_) return launch<M_, N_, 0, 0, 0, 1>(kk, st);
+      VIRNET_F16_ENT(2, 3) VIRNET_F16_ENT(2, 2) VIRNET_F16_ENT(2, 1) VIRNET_F16_ENT(1, 3) VIRNET_F16_ENT(1, 2) VIRNET_F16_ENT(1, 1)
+#undef VIRNET_F16_ENT
+    }
     if (te) {
 #define VIRNET_F16_TE(N_, E_) if (nrep == N_ && epi == E_) return bf ? launch<2, N_, E_, 1, 1>(kk, st) : launch<2, N_, E_, 0, 1>(kk, st);
 #define VIRNET_F16_TEN(N_) VIRNET_F16_TE(N_, 0) VIRNET_F16_TE(N_, 1) VIRNET_F16_TE(N_, 2) VIRNET_F16_TE(N_, 3)

@@ -53,7 +53,37 @@ struct FArgs {
   float* t_col;
   int t_cb, t_npl, t_nseg, t_nblk, t_act;
   float t_slope;
+  // Entry form (conv_f16.hip, ENT = 1): the image entry of virnet_pack_input folded into the conv's staging -- the 16-channel record
+  // [image | per-image vector | per-pixel map | 0] of a pixel is gathered from the NCHW sources instead of being read from a packed tensor
+  // (H, W above are the padded size hp x wp)
+  virnet_pack_desc ent;
 };
+
+// One pixel's first 8 record channels as virnet_pack_input writes them (pack.hip: nearest up-sampling, bottom / right reflect pad, sqrt of
+// the variance map, channel concat); (y, x) inside the padded image.  c0 + ev + em <= 8.
+__device__ __forceinline__ void entry_pixel(const virnet_pack_desc& d, int n, int y, int x, f32x4& r0, f32x4& r1) {
+  const int HU = d.h * d.sf, WU = d.w * d.sf;
+  const int ry = y < HU ? y : 2 * HU - 2 - y, rx = x < WU ? x : 2 * WU - 2 - x;
+  const bool dead = d.zero_pad && (y >= HU || x >= WU);
+  const int sy = d.sf == 1 ? ry : ry / d.sf, sx = d.sf == 1 ? rx : rx / d.sf;
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int c = k;
+    float val = 0.f;
+    if (c < d.c0) {
+      val = d.x[(((size_t)n * d.c0 + c) * d.h + sy) * d.w + sx];
+    } else if ((c -= d.c0) < d.ev) {
+      val = d.vec[(size_t)n * d.ev + c];
+    } else if ((c -= d.ev) < d.em) {
+      val = d.map[(((size_t)n * d.em + c) * d.mh + (d.msf == 1 ? ry : ry / d.msf)) * d.mw + (d.msf == 1 ? rx : rx / d.msf)];
+      if (d.map_sqrt) val = sqrtf(val);
+    }
+    v[k] = dead ? 0.f : val;
+  }
+  r0 = f32x4{v[0], v[1], v[2], v[3]};
+  r1 = f32x4{v[4], v[5], v[6], v[7]};
+}
 
 // segments per row of T (wgrad_f16.hip: t_nseg -- the pixels rounded up to whole 64-pixel steps, 32 for narrow images, + one pad segment each side)
 inline int t_nseg_of(int w) { return w <= 32 ? 6 : 8 * ((w + 63) / 64) + 2; }

@@ -59,8 +59,7 @@ def snet_forward(snet, x: Tensor, mode: str = "raw") -> Tensor:
     """mode 'raw': DnCNN.forward output; mode 'sigma': exp(clamp(.)) of it (VIRNet.py:43), fused where possible."""
     x = _prep(x, snet.in_channels)
     n, _, h, w = x.shape
-    rec = ops.pack_input(x, h, w)
-    _, cur = ops.conv_mfma(rec, snet.conv1.packed(), want_raw=False, want_act=True, slope=0.25)
+    cur = ops.conv_entry(x, snet.conv1.packed(), h, w, want_act=True, slope=0.25)      # DnCNN.py:38: entry packing folded into the conv
     for key in sorted(snet.mid_layer.keys(), key=int):
         _, cur = ops.conv_mfma(cur, snet.mid_layer[key].packed(), want_raw=False, want_act=True, slope=0.25)
     last = snet.conv_last
@@ -146,18 +145,22 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
             extra_vec = extra_vec.detach().contiguous()
     feed_head = mode in ("input", "both")
     feed_down = mode in ("down", "both")
-    rec = ops.pack_input(x_in, Hp, Wp, sf=sf, vec=extra_vec if feed_head else None,
-                         map_=extra_map if feed_head else None, map_sf=map_sf, map_sqrt=map_sqrt)
     cond = None
+    rec = None
     if feed_down:
         if extra_map is None:
             cond = _Cond(extra_vec, None, 0, ev)
         else:  # per-pixel conditioning: keep full-resolution padded records of the extra channels (AttResUNet.py:158,168)
+            rec = ops.pack_input(x_in, Hp, Wp, sf=sf, vec=extra_vec if feed_head else None,
+                                 map_=extra_map if feed_head else None, map_sf=map_sf, map_sqrt=map_sqrt)
             crec = rec if feed_head else ops.pack_input(x_in, Hp, Wp, sf=sf, vec=extra_vec, map_=extra_map,
                                                         map_sf=map_sf, map_sqrt=map_sqrt)
             cond = _Cond(None, crec, rnet.in_chn, ev + em)
-
-    x, _ = ops.conv_mfma(rec, rnet.head.packed(), want_raw=True)                       # AttResUNet.py:153-155
+    if rec is not None:
+        x, _ = ops.conv_mfma(rec, rnet.head.packed(), want_raw=True)                   # AttResUNet.py:153-155
+    else:                                                                              # ... with the entry packing folded into the conv
+        x = ops.conv_entry(x_in, rnet.head.packed(), Hp, Wp, sf=sf, vec=extra_vec if feed_head else None,
+                           map_=extra_map if feed_head else None, map_sf=map_sf, map_sqrt=map_sqrt)
     bridges: List[Tensor] = []
     for ii, lvl in enumerate(rnet.down_path):
         for blk in lvl.body:

@@ -105,7 +105,7 @@ DEFAULT_CONV_FORM = "wx4"
 
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
-_KNOBS = ("VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
+_KNOBS = ("VIRNET_ENTRY_FUSED", "VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
           "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
@@ -667,6 +667,45 @@ def pack_input(x: Tensor, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor
     d = nat.PackDesc(x=nat.ptr(x), vec=nat.ptr(vec), map=nat.ptr(map_), out=nat.ptr(out), n=n, c0=c0, h=h, w=w, sf=sf,
                      ev=ev, em=em, mh=mh, mw=mw, msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp, zero_pad=int(zero_pad))
     nat.check(nat.load().virnet_pack_input(C.byref(d), nat.stream_handle()), "pack_input")
+    return out
+
+
+def conv_entry(x: Tensor, pw: PackedWeight, hp: int, wp: int, *, sf: int = 1, vec: Optional[Tensor] = None, map_: Optional[Tensor] = None,
+               map_sf: int = 1, map_sqrt: bool = False, want_act: bool = False, slope: float = 0.2) -> Tensor:
+    """The network entry as ONE launch: ``conv3x3(pack_input(x, hp, wp, ...))`` (AttResUNet.head AttResUNet.py:153-155, DnCNN.conv1
+    DnCNN.py:38) with the 16-channel record gathered from the NCHW image / vector / map inside the conv's staging
+    (``virnet_conv_f16_entry``) -- no packed tensor, one launch less.  Returns the NHWC output (raw, or ``lrelu(., slope)`` with
+    ``want_act``).  Forms or channel counts without the fused kernel take the two-launch path; same bits either way."""
+    _dev_check(x, "x")
+    n, c0, h, w = x.shape
+    ev = 0 if vec is None else vec.shape[1]
+    em, mh, mw = (0, 0, 0) if map_ is None else map_.shape[1:]
+    kw = dict(want_raw=not want_act, want_act=want_act, slope=slope)
+    if not (_f16_family() and pw.f16 is not None and pw.cin_pad == 16 and pw.cout % 32 == 0 and c0 + ev + em <= 8
+            and _env("VIRNET_ENTRY_FUSED", "1") != "0"):
+        rec = pack_input(x, hp, wp, sf=sf, vec=vec, map_=map_, map_sf=map_sf, map_sqrt=map_sqrt)
+        raw, act = conv_mfma(rec, pw, **kw)
+        return act if want_act else raw
+    for t, nm in ((vec, "vec"), (map_, "map")):
+        if t is not None:
+            _dev_check(t, nm)
+    out = torch.empty((n, hp, wp, pw.cout), dtype=torch.float32, device=x.device)
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=nat.ptr(pw.bias), res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0,
+                     y_raw=0 if want_act else nat.ptr(out), y_act=nat.ptr(out) if want_act else 0, n=n, h=hp, w=wp, cin_pad=16, cout=pw.cout,
+                     n_pad=pw.n_pad, nrep=pw.nrep, ks=3, stride=1, epi=nat.EPI_NHWC, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=0,
+                     in_slope=0.0, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
+    e = nat.PackDesc(x=nat.ptr(x), vec=nat.ptr(vec), map=nat.ptr(map_), out=0, n=n, c0=c0, h=h, w=w, sf=sf, ev=ev, em=em, mh=mh, mw=mw,
+                     msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp, zero_pad=0)
+    lib = nat.load()
+    flops = 2.0 * n * hp * wp * pw.cin_real * pw.cout * 9
+    if _TIMER is None:
+        nat.check(lib.virnet_conv_f16_entry(C.byref(d), C.byref(e), nat.stream_handle()), "conv_f16_entry")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.check(lib.virnet_conv_f16_entry(C.byref(d), C.byref(e), nat.stream_handle()), "conv_f16_entry")
+        e1.record()
+        _TIMER.records.append((("f16x3", pw.cout), flops, e0, e1))
     return out
 
 
