@@ -65,18 +65,23 @@ __device__ __forceinline__ void entry_pixel(const virnet_pack_desc& d, int n, in
   const int HU = d.h * d.sf, WU = d.w * d.sf;
   const int ry = y < HU ? y : 2 * HU - 2 - y, rx = x < WU ? x : 2 * WU - 2 - x;
   const bool dead = d.zero_pad && (y >= HU || x >= WU);
-  const int sy = d.sf == 1 ? ry : ry / d.sf, sx = d.sf == 1 ? rx : rx / d.sf;
+  // image-uniform bases (scalar 64-bit arithmetic), 32-bit offsets inside one image's planes
+  const float* const xi = d.x + (size_t)n * d.c0 * d.h * d.w;
+  const float* const mi = d.em ? d.map + (size_t)n * d.em * d.mh * d.mw : nullptr;
+  const float* const vi = d.ev ? d.vec + (size_t)n * d.ev : nullptr;
+  const unsigned xpix = (unsigned)((d.sf == 1 ? ry : ry / d.sf) * d.w + (d.sf == 1 ? rx : rx / d.sf)), xplane = (unsigned)(d.h * d.w);
+  const unsigned mpix = d.em ? (unsigned)((d.msf == 1 ? ry : ry / d.msf) * d.mw + (d.msf == 1 ? rx : rx / d.msf)) : 0u, mplane = (unsigned)(d.mh * d.mw);
   float v[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     int c = k;
     float val = 0.f;
     if (c < d.c0) {
-      val = d.x[(((size_t)n * d.c0 + c) * d.h + sy) * d.w + sx];
+      val = xi[c * xplane + xpix];
     } else if ((c -= d.c0) < d.ev) {
-      val = d.vec[(size_t)n * d.ev + c];
+      val = vi[c];
     } else if ((c -= d.ev) < d.em) {
-      val = d.map[(((size_t)n * d.em + c) * d.mh + (d.msf == 1 ? ry : ry / d.msf)) * d.mw + (d.msf == 1 ? rx : rx / d.msf)];
+      val = mi[c * mplane + mpix];
       if (d.map_sqrt) val = sqrtf(val);
     }
     v[k] = dead ? 0.f : val;
