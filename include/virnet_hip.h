@@ -270,6 +270,10 @@ int virnet_chsplit(const float* x, int n, int h, int w, int c, int in_act, float
                    int bf16, void* out, float* col_scratch, float* db, int cvalid, void* stream);
 int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
                           int bf16, void* stream);
+/* ... and, in the same reduction launch, the bias gradient from the column partials an emitting convolution left for yt's tensor
+ * (virnet_t_emit.col, nblk from virnet_conv_emit_ok): db[c] += sum over blocks, c < cvalid (zero db first). */
+int virnet_conv_wgrad_f16_db(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                             int bf16, const float* col, float* db, long nblk, int cvalid, void* stream);
 /* The weight gradients of the two stride-2 layers on the same kernel (backward of DownBlock.downsampler networks/AttResUNet.py:67 and
  * UpBlock.upsampler :80).  The HIGH-resolution operand [n][h][w][c] (c % 32 == 0, w even) is re-laid by virnet_chsplit_s2 into a
  * column-phase T: one row per source row, [h+2][2*c/32 blocks][hi|lo][seg(w/2)][32 ch][8 px], block par*c/32 + k = the pixels

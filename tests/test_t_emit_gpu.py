@@ -69,12 +69,12 @@ def test_emitted_image_is_the_chsplit_of_the_stored_tensor(form, n, h, w, c, epi
     diff = int((ref != timg.buf).sum())
     assert diff == 0, f"{diff} of {ref.numel()} bytes differ"
     colsum = y.double().sum((0, 1, 2))
-    assert float((timg.db.double() - colsum).abs().max()) <= 2e-5 * max(1.0, float(colsum.abs().max()))
+    assert float((timg.bias_sums().double() - colsum).abs().max()) <= 2e-5 * max(1.0, float(colsum.abs().max()))
     # pooled buffers: a released image comes back with clean pads even after a different tensor went through it
     ops.t_release(timg)
     _, _, t2 = ops.conv_mfma(x * 0.5, cp.packed(), emit=dict(act=tslope, colsum=None), **kw)
     y2 = ops.conv_mfma(x * 0.5, cp.packed(), **kw)[1 if want_act else 0]
-    assert t2.db is None and torch.equal(chsplit_ref(y2, form == "bf16", tslope), t2.buf)
+    assert t2.bias_sums() is None and torch.equal(chsplit_ref(y2, form == "bf16", tslope), t2.buf)
 
 
 def test_small_or_unsupported_launches_fall_back(monkeypatch):

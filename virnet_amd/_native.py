@@ -141,6 +141,8 @@ SYMBOLS = [
     ("virnet_conv_f16_emit", C.c_int, [C.POINTER(ConvDesc), C.POINTER(TEmit), C.c_int, C.c_void_p]),
     ("virnet_conv_wx4_emit", C.c_int, [C.POINTER(ConvDesc), C.POINTER(TEmit), C.c_void_p]),
     ("virnet_colpart_reduce", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    ("virnet_conv_wgrad_f16_db", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
     ("virnet_colsum", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_zero_stuff2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("virnet_space_to_depth2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

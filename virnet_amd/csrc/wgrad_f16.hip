@@ -118,6 +118,22 @@ __global__ __launch_bounds__(256) void chsplit_kernel(const float* __restrict__ 
 }
 
 // db[cb*32 + ch] += sum over blocks of colpart[cb][blk][ch]; grid (cb, slices)
+__device__ __forceinline__ void colpart_reduce_block(const float* __restrict__ part, float* __restrict__ db, long nblk, int cvalid, int cbh,
+                                                     int cb, int slice, int nslices, float (*red)[32]) {
+  const int j = threadIdx.x >> 5, ch = threadIdx.x & 31;
+  float t = 0.f;
+  for (long blk = (long)slice * 8 + j; blk < nblk; blk += (long)nslices * 8) t += part[((size_t)cb * nblk + blk) * 32 + ch];
+  red[j][ch] = t;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u += red[k][threadIdx.x];
+    const int c = (cb % cbh) * 32 + threadIdx.x;
+    if (c < cvalid) atomicAdd(db + c, u);
+  }
+}
+
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ db, long nblk, int cvalid, int cbh) {
   __shared__ float red[8][32];
   const int cb = blockIdx.x, j = threadIdx.x >> 5, ch = threadIdx.x & 31;
@@ -460,8 +476,27 @@ __global__ __launch_bounds__(64 * KG * NWV) __attribute__((amdgpu_waves_per_eu(3
 // dw[co][ci][t] = sum over runs of part[run][t][co][ci]   (thread = one (t, co, ci); consecutive threads = consecutive ci).
 // Latency-bound (one dependent chain of nrun loads per thread): sixteen loads in flight per thread; the partial sums are added in
 // run order within each of the sixteen strided chains and the chains in a fixed tree -> bitwise reproducible.
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin, int blk);
+
+// the weight gradient's partial-sum reduction and (blocks behind it) the bias gradient's column-partial reduction in ONE launch: a training
+// step makes ~45 of each, every one a few microseconds of work behind a launch
+__global__ __launch_bounds__(256) void wgrad_reduce_db_kernel(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin,
+                                                              int nred, const float* __restrict__ col, float* __restrict__ db, long nblk, int cvalid, int ncb, int nslices) {
+  __shared__ float red[8][32];
+  if ((int)blockIdx.x < nred) {
+    wgrad_reduce_body(part, dw, nrun, cop, cip, cout, cin, blockIdx.x);
+  } else {
+    const int q = blockIdx.x - nred;
+    colpart_reduce_block(col, db, nblk, cvalid, ncb, q / nslices, q % nslices, nslices, red);
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  wgrad_reduce_body(part, dw, nrun, cop, cip, cout, cin, blockIdx.x);
+}
+
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int nrun, int cop, int cip, int cout, int cin, int blk) {
+  const int i = blk * 256 + threadIdx.x;
   const int per = 9 * cop * cip;
   if (i >= per) return;
   const int ci = i % cip, co = (i / cip) % cop, t = i / (cip * cop);
@@ -618,8 +653,22 @@ extern "C" int virnet_chsplit_s2(const float* x, int n, int h, int w, int c, int
   return chsplit_launch(x, n, h, w, c, in_act, in_slope, in_mul, in_add, bf16, out, col_scratch, db, cvalid, stream, 1);
 }
 
+static int conv_wgrad_f16_impl(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                               int bf16, const float* col, float* db, long nblk, int cvalid, void* stream);
+
 extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
                                      int bf16, void* stream) {
+  return conv_wgrad_f16_impl(xt, yt, dw, scratch, n, h, w, cx, cy, cin, cout, bf16, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int virnet_conv_wgrad_f16_db(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                                        int bf16, const float* col, float* db, long nblk, int cvalid, void* stream) {
+  VIRNET_REQUIRE(col && db && nblk > 0 && cvalid >= 1 && cvalid <= cy, "virnet_conv_wgrad_f16_db: bad column-partial arguments (nblk=%ld cvalid=%d)", nblk, cvalid);
+  return conv_wgrad_f16_impl(xt, yt, dw, scratch, n, h, w, cx, cy, cin, cout, bf16, col, db, nblk, cvalid, stream);
+}
+
+static int conv_wgrad_f16_impl(const void* xt, const void* yt, float* dw, float* scratch, int n, int h, int w, int cx, int cy, int cin, int cout,
+                               int bf16, const float* col, float* db, long nblk, int cvalid, void* stream) {
   VIRNET_REQUIRE(xt && yt && dw && scratch, "virnet_conv_wgrad_f16: NULL pointer");
   VIRNET_REQUIRE(n > 0 && h > 4 && w > 0, "virnet_conv_wgrad_f16: h=%d (the row ring needs h >= 5) or empty input", h);
   VIRNET_REQUIRE(cin >= 1 && cin <= cx && cout >= 1 && cout <= cy, "virnet_conv_wgrad_f16: cin=%d / cout=%d beyond the stored %d / %d channels", cin, cout, cx, cy);
@@ -637,7 +686,14 @@ extern "C" int virnet_conv_wgrad_f16(const void* xt, const void* yt, float* dw, 
   else rc = bf16 ? launch_nwv<1, 4>(kk, p, st) : launch_nwv<0, 4>(kk, p, st);
   if (rc) return rc;
   const int cop = kk.ncob * 32, cip = kk.ncib * 32;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * cop * cip + 255) / 256), dim3(256), 0, st, scratch, dw, p.split, cop, cip, cout, cin);
+  const int nred = (9 * cop * cip + 255) / 256;
+  if (col) {
+    const int slices = (int)(nblk / 64 < 1 ? 1 : nblk / 64 > 64 ? 64 : nblk / 64);
+    hipLaunchKernelGGL(wgrad_reduce_db_kernel, dim3(nred + kk.ncob * slices), dim3(256), 0, st, scratch, dw, p.split, cop, cip, cout, cin, nred,
+                       col, db, nblk, cvalid, kk.ncob, slices);
+    return virnet::check_launch("wgrad_reduce_db launch");
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nred), dim3(256), 0, st, scratch, dw, p.split, cop, cip, cout, cin);
   return virnet::check_launch("wgrad_reduce launch");
 }
 

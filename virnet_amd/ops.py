@@ -105,7 +105,7 @@ DEFAULT_CONV_FORM = "wx4"
 
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
-_KNOBS = ("VIRNET_ENTRY_FUSED", "VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
+_KNOBS = ("VIRNET_BIAS_FUSED", "VIRNET_ENTRY_FUSED", "VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
           "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
@@ -425,6 +425,20 @@ class TImage:
     bf16: bool
     db: Optional[Tensor] = None
     pooled: bool = False
+    # channel sums still pending as per-workgroup partials (the emitting conv left them; the consuming weight gradient reduces them in
+    # its own reduction launch -- or bias_sums() on demand): col[(cb * nblk + blk) * 32 + ch], ncol = channels asked for
+    col: Optional[Tensor] = None
+    nblk: int = 0
+    ncol: int = 0
+
+    def bias_sums(self) -> Optional[Tensor]:
+        """The tensor's channel sums (bias gradient), reducing the pending partials if nothing has done so yet."""
+        if self.db is None and self.col is not None:
+            self.db = torch.zeros(self.ncol, dtype=torch.float32, device=self.col.device)
+            nat.check(nat.load().virnet_colpart_reduce(nat.ptr(self.col), nat.ptr(self.db), self.nblk, self.c // 32, self.ncol, nat.stream_handle()),
+                      "colpart_reduce")
+            self.col = None
+        return self.db
 
 
 _T_POOL: dict = {}
@@ -538,14 +552,17 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
         col = None
         ncol = emit.get("colsum")
         if ncol is not None:
-            col = _workspace("emit_col", nblk.value * cstore * 4, x.device)
-            timg.db = torch.zeros(ncol, dtype=torch.float32, device=x.device)
+            # two alternating buffers: the partials wait for the weight gradient that consumes this image, and at most one other
+            # emitting conv runs before it (train.py: dgrad conv -> wgrad of the previous conv -> next dgrad conv)
+            turn = nat.tls.emit_col_turn = getattr(nat.tls, "emit_col_turn", 0) ^ 1          # (per host thread, like the workspaces' streams)
+            col = _workspace("emit_col%d" % turn, nblk.value * cstore * 4, x.device)
+            timg.col, timg.nblk, timg.ncol = col, nblk.value, ncol
         slope_t = emit.get("act")
         te = nat.TEmit(t_out=nat.ptr(timg.buf), col=nat.ptr(col), act=int(slope_t is not None), slope=0.0 if slope_t is None else slope_t,
                        bf16=int(form == "bf16"), rows=rows)
         _launch_conv(d, flops, what + "(+T)", form, te)
-        if col is not None:
-            nat.check(lib.virnet_colpart_reduce(nat.ptr(col), nat.ptr(timg.db), nblk.value, cstore // 32, ncol, nat.stream_handle()), "colpart_reduce")
+        if col is not None and _env("VIRNET_BIAS_FUSED", "1") == "0":
+            timg.bias_sums()                             # (A/B knob: reduce the partials now, in a launch of their own)
     else:
         _launch_conv(d, flops, what, form)
     return raw, act, timg
@@ -972,7 +989,8 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
         xt = None                                           # (emitted by a conv of the other operand form: re-lay it)
     if yt is not None and yt.bf16 != bf16:
         yt = None
-    if yt is not None and bias_channels is not None and (yt.db is None or yt.db.numel() != bias_channels):
+    if yt is not None and bias_channels is not None and not ((yt.db is not None and yt.db.numel() == bias_channels)
+                                                             or (yt.col is not None and yt.ncol == bias_channels)):
         yt = None                                           # (no channel sums came with it: take the pass that produces them)
     timed = _TIMER is not None
     if timed:
@@ -995,9 +1013,15 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
     else:
         ybuf = yt.buf
         db = yt.db if bias_channels is not None else None
-    xt, yt = xbuf, ybuf
+    pending = yt is not None and bias_channels is not None and db is None          # partials the emitting conv left: reduced in OUR reduce launch
     scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_scratch_bytes(n, h, w, cx, cy), x.device)
-    nat.check(lib.virnet_conv_wgrad_f16(nat.ptr(xt), nat.ptr(yt), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16), st), "conv_wgrad_f16")
+    if pending:
+        db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
+        nat.check(lib.virnet_conv_wgrad_f16_db(nat.ptr(xbuf), nat.ptr(ybuf), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16),
+                                               nat.ptr(yt.col), nat.ptr(db), yt.nblk, bias_channels, st), "conv_wgrad_f16_db")
+        yt.db, yt.col = db, None
+    else:
+        nat.check(lib.virnet_conv_wgrad_f16(nat.ptr(xbuf), nat.ptr(ybuf), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16), st), "conv_wgrad_f16")
     if timed:
         e1.record()
         _TIMER.records.append((("wgrad_f16", 3, 1, 0), 2.0 * n * h * w * cin * cout * 9, e0, e1))
@@ -1019,7 +1043,7 @@ def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope
     # the low-resolution operand as an image a convolution already emitted (plain layout): usable when it is exactly the image this call
     # would build -- for the stride-2 conv it must bring the channel sums (its dY's bias gradient) along
     if lo_t is not None and ((lo_t.n, lo_t.h, lo_t.w, lo_t.c) != (n, oh, ow, clo) or lo_t.bf16 != bf16 or lo_t.buf is None
-                             or (mode == 0 and bias_channels is not None and (lo_t.db is None or lo_t.db.numel() != bias_channels))):
+                             or (mode == 0 and bias_channels is not None and (lo_t.ncol if lo_t.db is None else lo_t.db.numel()) != bias_channels)):
         lo_t = None
     ht = _workspace("wgrad_xt", lib.virnet_chsplit_s2_bytes(n, hh, hw, chi), hi.device)
     lt = lo_t.buf if lo_t is not None else _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, oh, ow, clo), hi.device)
@@ -1034,7 +1058,7 @@ def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope
         if mode == 1:
             hcol = _workspace("wgrad_col", lib.virnet_chsplit_s2_colsum_bytes(n, hh, hw, chi), hi.device)
         elif lo_t is not None:
-            db = lo_t.db
+            db = lo_t.bias_sums()
         else:
             lcol = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, oh, ow, clo), hi.device)
     bc = 0 if bias_channels is None else bias_channels
