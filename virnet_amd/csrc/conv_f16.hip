@@ -433,9 +433,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       }
       if constexpr (TE) {
         // thread (cq, psub) holds 8 consecutive pixels of tile row wave*MREP + (psub >> 2), x-segment psub & 3, for 4 channels
-        const int trow = oy0 + wave * MREP + (psub >> 2);
         const int cbg = (nbase >> 5) + nr;                      // 32-channel block of the stored tensor
-        char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + (psub & 3) + 1)) * 512 + cq * 64;
         f32x4 cs = zero4;
         u32x4 uh[4], ul[4];
 #pragma unroll
@@ -449,16 +447,31 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
           }
           t_units(e8, BF != 0, uh[c], ul[c]);
         }
-        // lane cq writes the units of its channels 4cq .. 4cq+3: 64 contiguous bytes per lane and plane, 512 per 8 lanes.  (Measured:
-        // a DPP quad transpose that makes every single store instruction lane-contiguous costs more than it saves -- training step
-        // 24.9 -> 27.7 ms fp32-class, 17.2 -> 18.5 bf16, profiles/r04_probes.md 8.)
-        if (trow < a.H) {
-          char* const tq = tb - cq * 64;
+        // Re-coalesce the wave's units through ITS turn-around region of this slab (free: every lane has read its items; wave-private, so the
+        // wave's in-order LDS pipe is the only ordering needed): written in T's order [row 2][plane][x-segment 4][32 ch], read back lane-linear --
+        // a store instruction then covers 1 KB of contiguous T instead of 64 pieces of 16 B that sit 64 B apart (profiles/r04_probes.md 8).
+        // (A DPP quad transpose with the same effect cost more than it saved: 24.9 -> 27.7 ms fp32-class, 17.2 -> 18.5 bf16.)
+        {
+          constexpr int NPL = BF ? 1 : 2;
+          char* const ub = tbuf + (nr & 1) * TREG;
+          const int urow = psub >> 2, uxq = psub & 3;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(tq + (4 * cq + i) * 16) = uh[i];
-            if (!BF) *reinterpret_cast<u32x4*>(tq + (size_t)a.t_nseg * 512 + (4 * cq + i) * 16) = ul[i];
+            *reinterpret_cast<u32x4*>(ub + ((((urow * NPL + 0) * 4 + uxq) * 32 + 4 * cq + i) << 4)) = uh[i];
+            if (!BF) *reinterpret_cast<u32x4*>(ub + ((((urow * NPL + 1) * 4 + uxq) * 32 + 4 * cq + i) << 4)) = ul[i];
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          char* const t0 = a.t_out + ((((size_t)img * (a.H + 2) + oy0 + wave * MREP + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + 1)) * 512;
+          const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
+#pragma unroll
+          for (int k = 0; k < 4 * NPL; ++k) {
+            const int u = k * 64 + lane;                       // unit: channel u & 31, x-segment (u >> 5) & 3, (row, plane) = u >> 7
+            const int rp = u >> 7, r = rp / NPL, pl = rp - r * NPL;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ub + (u << 4));
+            if (oy0 + wave * MREP + r < a.H)
+              *reinterpret_cast<u32x4*>(t0 + r * trow_bytes + (size_t)pl * a.t_nseg * 512 + ((u >> 5) & 3) * 512 + (u & 31) * 16) = v;
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the region is the next-but-one slab's turn-around buffer)
         }
         if (a.t_col) {                                          // wave's channel sums: the 8 psub lanes of a channel quad, then one row per wave
 #pragma unroll

@@ -571,9 +571,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
         // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
       if constexpr (TE) {
-        const int trow = oy0 + te_row;
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
-        char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + te_xq + 1)) * 512 + cq * 64;
         f32x4 cs = zero4;
         u32x4 uh[4], ul[4];
 #pragma unroll
@@ -587,16 +585,24 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
           }
           t_units(e8, false, uh[c], ul[c]);
         }
-#ifdef VIRNET_TE_NOSTORE
-        if (trow < a.H && a.t_nseg < 0) {                    // probe build: everything but the T stores
-#else
-        if (trow < a.H) {
-#endif
-          char* const tq = tb - cq * 64;
+        // Re-coalesce the slab's 4096 units through LDS (conv_f16_wx4h.hip): T's own order [row][plane][x-segment][32 ch], read back lane-linear
+        wx_lds_barrier();
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(tq + (4 * cq + i) * 16) = uh[i];
-            *reinterpret_cast<u32x4*>(tq + (size_t)a.t_nseg * 512 + (4 * cq + i) * 16) = ul[i];
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<u32x4*>(xb + ((((te_row * 2 + 0) * 4 + te_xq) * 32 + 4 * cq + i) << 4)) = uh[i];
+          *reinterpret_cast<u32x4*>(xb + ((((te_row * 2 + 1) * 4 + te_xq) * 32 + 4 * cq + i) << 4)) = ul[i];
+        }
+        wx_lds_barrier();
+        {
+          char* const tile0 = a.t_out + ((((size_t)img * (a.H + 2) + oy0 + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + 1)) * 512;
+          const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
+          const int uch = tid & 31, uxq = (tid >> 5) & 3, upl = (tid >> 7) & 1, urow = tid >> 8;   // unit u = k*512 + tid: row 2k + (tid>>8)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 512 + tid) << 4));
+            const int r = 2 * k + urow;
+            if (oy0 + r < a.H)
+              *reinterpret_cast<u32x4*>(tile0 + r * trow_bytes + (size_t)upl * a.t_nseg * 512 + uxq * 512 + uch * 16) = v;
           }
         }
         if (a.t_col) {                                      // wave's channel sums (its 8 lanes per channel quad), one row per wave

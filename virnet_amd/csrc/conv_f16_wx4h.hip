@@ -496,9 +496,11 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
       for (int it = 0; it < NIT; ++it)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
       if constexpr (TE) {
-        const int trow = oy0 + te_row;
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
+#ifdef VIRNET_TE_DIRECT
+        const int trow = oy0 + te_row;
         char* const tb = a.t_out + ((((size_t)img * (a.H + 2) + trow + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + te_xq + 1)) * 512 + cq * 64;
+#endif
         f32x4 cs = zero4;
         u32x4 uh[4], ul[4];
 #pragma unroll
@@ -512,13 +514,37 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
           }
           t_units(e8, false, uh[c], ul[c]);
         }
-        if (trow < a.H) {
+#ifdef VIRNET_TE_DIRECT
+        if (trow < a.H) {                                   // (A/B build: every lane stores its own 4 x 16 B per plane, 64 B apart from its neighbour's)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<u32x4*>(tb + i * 16) = uh[i];
             *reinterpret_cast<u32x4*>(tb + (size_t)a.t_nseg * 512 + i * 16) = ul[i];
           }
         }
+#else
+        // Re-coalesce the slab's 2048 units through LDS (the exchange region is free once every thread has read its items): written in T's own
+        // order [row][plane][x-segment][32 ch], read back lane-linear, so that a store instruction covers 1 KB of contiguous T instead of 64
+        // pieces of 16 B that sit 64 B apart (the emitted image's stores were the whole cost of the emission: profiles/r04_probes.md 8)
+        wx_lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          *reinterpret_cast<u32x4*>(xb + ((((te_row * 2 + 0) * 4 + te_xq) * 32 + 4 * cq + i) << 4)) = uh[i];
+          *reinterpret_cast<u32x4*>(xb + ((((te_row * 2 + 1) * 4 + te_xq) * 32 + 4 * cq + i) << 4)) = ul[i];
+        }
+        wx_lds_barrier();
+        {
+          char* const tile0 = a.t_out + ((((size_t)img * (a.H + 2) + oy0 + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + 1)) * 512;
+          const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
+          const int uch = tid & 31, uxq = (tid >> 5) & 3, upl = tid >> 7;         // unit u = k*256 + tid: row k, plane tid>>7, x-segment, channel
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 256 + tid) << 4));
+            if (oy0 + k < a.H)
+              *reinterpret_cast<u32x4*>(tile0 + k * trow_bytes + (size_t)upl * a.t_nseg * 512 + uxq * 512 + uch * 16) = v;
+          }
+        }
+#endif
         if (a.t_col) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
