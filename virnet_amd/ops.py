@@ -434,7 +434,7 @@ class TImage:
     def bias_sums(self) -> Optional[Tensor]:
         """The tensor's channel sums (bias gradient), reducing the pending partials if nothing has done so yet."""
         if self.db is None and self.col is not None:
-            self.db = torch.zeros(self.ncol, dtype=torch.float32, device=self.col.device)
+            self.db = _zeros(self.ncol, self.col.device)
             nat.check(nat.load().virnet_colpart_reduce(nat.ptr(self.col), nat.ptr(self.db), self.nblk, self.c // 32, self.ncol, nat.stream_handle()),
                       "colpart_reduce")
             self.col = None
@@ -458,6 +458,32 @@ def t_release(t: Optional[TImage]) -> None:
         dev = t.buf.device
         _T_POOL.setdefault((dev.index, torch.cuda.current_stream(dev).cuda_stream, t.n, t.h, t.w, t.c), []).append(t.buf)
         t.buf = None
+
+
+class zero_arena:
+    """`with ops.zero_arena(n, device):` -- the small zero-initialised fp32 vectors the block asks for (bias gradients: ~45 per training
+    step, each a fill launch of its own otherwise) are carved out of ONE zeroed buffer; beyond its size `torch.zeros` takes over."""
+
+    def __init__(self, nfloats: int, device: torch.device):
+        self.n, self.device = int(nfloats), device
+
+    def __enter__(self):
+        self._prev = getattr(nat.tls, "zero_arena", None)
+        nat.tls.zero_arena = [torch.zeros(self.n, dtype=torch.float32, device=self.device), 0] if self.n > 0 else None
+        return self
+
+    def __exit__(self, *exc):
+        nat.tls.zero_arena = self._prev
+        return False
+
+
+def _zeros(n: int, device: torch.device) -> Tensor:
+    ar = getattr(nat.tls, "zero_arena", None)
+    if ar is not None and ar[0].device == device and ar[1] + n <= ar[0].numel():
+        out = ar[0][ar[1]:ar[1] + n]
+        ar[1] += n
+        return out
+    return torch.zeros(n, dtype=torch.float32, device=device)
 
 
 def t_pool_clear() -> None:
@@ -1006,7 +1032,7 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
     if yt is None:
         ybuf = _workspace("wgrad_yt", lib.virnet_chsplit_bytes(n, h, w, cy), x.device)
         if bias_channels is not None:
-            db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
+            db = _zeros(bias_channels, x.device)
             col = _workspace("wgrad_col", lib.virnet_chsplit_colsum_bytes(n, h, w, cy), x.device)
         nat.check(lib.virnet_chsplit(nat.ptr(dy), n, h, w, cy, 0, 0.0, None, None, int(bf16), nat.ptr(ybuf), nat.ptr(col), nat.ptr(db),
                                      0 if bias_channels is None else bias_channels, st), "chsplit")
@@ -1016,7 +1042,7 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
     pending = yt is not None and bias_channels is not None and db is None          # partials the emitting conv left: reduced in OUR reduce launch
     scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_scratch_bytes(n, h, w, cx, cy), x.device)
     if pending:
-        db = torch.zeros(bias_channels, dtype=torch.float32, device=x.device)
+        db = _zeros(bias_channels, x.device)
         nat.check(lib.virnet_conv_wgrad_f16_db(nat.ptr(xbuf), nat.ptr(ybuf), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16),
                                                nat.ptr(yt.col), nat.ptr(db), yt.nblk, bias_channels, st), "conv_wgrad_f16_db")
         yt.db, yt.col = db, None
@@ -1054,7 +1080,7 @@ def _conv_wgrad_f16_s2(hi: Tensor, lo: Tensor, weight_shape, mode: int, in_slope
     db = None
     hcol = lcol = None
     if bias_channels is not None:
-        db = torch.zeros(bias_channels, dtype=torch.float32, device=hi.device)
+        db = _zeros(bias_channels, hi.device)
         if mode == 1:
             hcol = _workspace("wgrad_col", lib.virnet_chsplit_s2_colsum_bytes(n, hh, hw, chi), hi.device)
         elif lo_t is not None:
@@ -1087,7 +1113,7 @@ def colsum(dy: Tensor, cvalid: Optional[int] = None) -> Tensor:
     _dev_check(dy, "dy")
     c = dy.shape[-1]
     cvalid = c if cvalid is None else cvalid
-    db = torch.zeros(cvalid, dtype=torch.float32, device=dy.device)
+    db = _zeros(cvalid, dy.device)
     nat.check(nat.load().virnet_colsum(nat.ptr(dy), nat.ptr(db), dy.numel() // c, c, cvalid, nat.stream_handle()), "colsum")
     return db
 

@@ -331,7 +331,9 @@ class DenoiseFunction(torch.autograd.Function):
             dsigma = None if dsigma is None else dsigma * scale
             if reducer is not None:
                 reducer.start()
-            grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma, reducer=reducer)
+            nbias = sum(p.numel() for p in ctx.params if p.dim() == 1)      # every bias gradient out of ONE zeroed buffer (45 fill launches less)
+            with ops.zero_arena(nbias + 64, dev):
+                grads = denoise_backward(ctx.net, ctx.tape, dmu, dsigma, reducer=reducer)
             side = _side_stream(dev)
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)      # gradients produced on the side stream are consumed after this
