@@ -299,6 +299,15 @@ int launch(FArgs k, hipStream_t st) {
 
 // Slabs per workgroup: 6 (8 waves) where the count allows, then 3 / 2 / 1 with 4 waves (288 channels = 6 + 3, 160 = 3 + 2, 224 = 6 + ... 3 + 2 + 2).
 int virnet::launch_f16_s2(FArgs k, int nb, hipStream_t st) {
+  // 160 and 224 channels (SISR: 5 / 7 slabs) as ONE 4-wave launch with 5 / 7 slabs per workgroup (the pixel tile staged once) instead of
+  // 3 + 2 / 3 + 2 + 2: the workgroup is alone on its CU either way (75 KB pixel tiles), so its 512 registers per wave are there
+  static const bool wide_off = getenv("VIRNET_S2_WIDE") && getenv("VIRNET_S2_WIDE")[0] == '0';      // (A/B knob)
+  if ((nb == 5 || nb == 7 || nb == 4) && !wide_off) {
+    FArgs kk = k;
+    kk.slab_base = 0;
+    kk.NP = nb * 32;
+    return nb == 5 ? launch<1, 5>(kk, st) : nb == 7 ? launch<1, 7>(kk, st) : launch<1, 4>(kk, st);
+  }
   int n6 = nb / 6, rem = nb - 6 * n6;
   // Small launches (single images): with 6 slabs per workgroup a 64x64 output is 32 workgroups on a 256-CU chip (and 288 channels two
   // such launches back to back: 48 + 36 us measured); 3-slab workgroups triple the grid and put all slabs in ONE launch.  The slab
