@@ -254,7 +254,7 @@ def main():
     out = ["// GENERATED by tools/gen_wx4h_sched.py (CAP=%d, LDS_LAT=%d, HEAD_CAP=%d) -- do not edit; see that script for the model." % (CAP, LDS_LAT, HEAD_CAP),
            "// WX4H_STAGE_<NREP>_<ji>_<PRE>: the body of one stage of conv_wx4h_kernel as fenced issue slots, one per MFMA, with the group",
            "// barriers gbar(dy, K) / gend(K) (K = vmcnt of the wait for the next group's weight pieces); WX4H_FINAL_<NREP>_<ji>: last chunk.", ""]
-    for nrep in (1, 2, 3):
+    for nrep in (1, 2, 3, 5):
         x0 = {}
         for ji in range(3):
             for pre in (0, 1, 2):

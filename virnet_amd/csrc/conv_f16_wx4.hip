@@ -864,7 +864,7 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
 #undef VIRNET_WX4_TE
       return virnet::set_error("virnet_conv_wx4_emit: no emitting kernel for nrep=%d epi=%d pre=%d", nrep, epi, pre);
     }
-    if (half_tiles_for(nrep, groups)) return virnet::launch_wx4h(kk, nrep, epi, pre, st);
+    if (nrep == 5 || half_tiles_for(nrep, groups)) return virnet::launch_wx4h(kk, nrep, epi, pre, st);
 #define VIRNET_WX4_EPI(N_, E_)                                                                                               \
     if (epi == E_) return pre == 2 ? launch_wx4<N_, E_, 2>(kk, st) : pre == 1 ? launch_wx4<N_, E_, 1>(kk, st) : launch_wx4<N_, E_, 0>(kk, st);
 #define VIRNET_WX4_CASE(N_)                                                                              \
@@ -876,6 +876,10 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
 #undef VIRNET_WX4_EPI
     return virnet::set_error("virnet_conv_wx4: no kernel for nrep=%d", nrep);
   };
+  // 160 channels (SISR level 1): five slabs in ONE launch of the 8-row form with one workgroup per CU (conv_f16_wx4h.hip, NREP = 5) instead
+  // of 3 + 2 slabs in two launches that each stage and transform the pixel tile.  VIRNET_WX4_WIDE=0: the two launches.
+  if (nb == 5 && rows_pin != 16 && !te && !(getenv("VIRNET_WX4_WIDE") && getenv("VIRNET_WX4_WIDE")[0] == '0') && !getenv("VIRNET_WX4_NREP"))
+    return run(5, 0, 1);
   if (int rc = run(3, 0, n3)) return rc;
   if (int rc = run(2, 3 * n3, n2)) return rc;
   return run(1, 3 * n3 + 2 * n2, n1);

@@ -36,7 +36,9 @@ constexpr int WH_CHUNK_BYTES = 36 * 1024;    // one slab's weights of one 16-cha
 // TE = 1: T emission (conv_f16_wx4.hip / conv_f16.hip): epilogue items = 8 consecutive pixels of one row, thread = (row of 8, x-segment of 4,
 // channel quad).  With two workgroups per CU the emitted image's stores run beside the other workgroup's K loop.
 template <int NREP, int EPI, int PRE, int TE = 0>
-__global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
+__global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const FArgs a) {
+  // NREP = 5 (SISR's 160 channels as ONE launch instead of 3 + 2 slabs): one workgroup per CU, one wave per SIMD -- 512 registers per wave
+  // hold the 15 accumulator blocks, 110 KB of LDS the 20-KB ring slots; the pixel tile is staged and transformed once for all five slabs
   static_assert(!TE || EPI < 4, "T emission: single-store epilogues");
   constexpr int NB = 32 * NREP;
   constexpr int GRP = 4 * NREP * 1024;             // one ring slot: [jt][slab][hi|lo][1 KB]
@@ -283,6 +285,10 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
   hP(WX_I(0)); hHi(); hSub(); hLo(); hSt(WX_I(0));
   hP(WX_I(1)); hHi(); hSub(); hLo(); hSt(WX_I(1));
   if (tid < 2 * NB) sb_lds[tid] = sbv;
+  if constexpr (2 * NB > 256) {                     // (five slabs: 320 table entries for 256 threads)
+    const int t2 = tid + 256;
+    if (t2 < 2 * NB) sb_lds[t2] = a.bias ? a.bias[nbase + t2 - NB] : 0.f;
+  }
   if constexpr (PRE == 2) {
     for (int i = tid; i < a.Cin; i += 256) { sft_lds[i] = imul[i]; sft_lds[a.Cin + i] = iadd[i]; }
   }
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void conv_wx4h_kernel(const FArgs a) {
     WXH_STAGE_PRE(1, 0) WXH_STAGE_PRE(1, 1) WXH_STAGE_PRE(1, 2)
     WXH_STAGE_PRE(2, 0) WXH_STAGE_PRE(2, 1) WXH_STAGE_PRE(2, 2)
     WXH_STAGE_PRE(3, 0) WXH_STAGE_PRE(3, 1) WXH_STAGE_PRE(3, 2)
+    WXH_STAGE_PRE(5, 0) WXH_STAGE_PRE(5, 1) WXH_STAGE_PRE(5, 2)
 #undef WXH_STAGE_PRE
 #undef WXH_STAGE_CASE
 #undef WX_TS
@@ -597,7 +604,7 @@ int launch_wx4h_t(FArgs k, hipStream_t st) {
   constexpr int LDS_K = WH_VBYTES + 4 * 4 * NREP * 1024;
   constexpr int LDS_E = 12 * WH_XBLK;
   constexpr int LDS = (LDS_K > LDS_E ? LDS_K : LDS_E) + 2 * 32 * NREP * 4;      // + the channel block's inverse scales and biases
-  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(LDS <= (NREP > 3 ? 158 : 80) * 1024, "two workgroups per CU (five-slab form: one)");
   static unsigned long long attr_done = 0;
   auto kern = conv_wx4h_kernel<NREP, EPI, PRE, TE>;
   if (virnet::first_use_on_device(attr_done)) {
@@ -641,7 +648,7 @@ int launch_wx4h(FArgs k, int nrep, int epi, int pre, hipStream_t st) {
   if (nrep == N_) {                                                                                      \
     VIRNET_WX4H_EPI(N_, 0) VIRNET_WX4H_EPI(N_, 1) VIRNET_WX4H_EPI(N_, 2) VIRNET_WX4H_EPI(N_, 3) VIRNET_WX4H_EPI(N_, 4)                    \
   }
-  VIRNET_WX4H_CASE(3) VIRNET_WX4H_CASE(2) VIRNET_WX4H_CASE(1)
+  VIRNET_WX4H_CASE(3) VIRNET_WX4H_CASE(2) VIRNET_WX4H_CASE(1) VIRNET_WX4H_CASE(5)
 #undef VIRNET_WX4H_CASE
 #undef VIRNET_WX4H_EPI
   return virnet::set_error("virnet_conv_wx4 (8-row tiles): no kernel for nrep=%d", nrep);
