@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from virnet_amd import dist as vdist  # noqa: E402
+from virnet_amd import engine  # noqa: E402
 from virnet_amd import ops  # noqa: E402
 from virnet_amd.networks import VIRAttResUNet, VIRAttResUNetSR  # noqa: E402
 from virnet_amd.utils.synth import synth_images, synth_state_dict  # noqa: E402
@@ -230,6 +231,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="default N=1 denoise run: skip the `steady_state` re-measurement and the `configs` "
                     "block (BASELINE configs[1], [3], [4] timed by child runs of this script)")
+    ap.add_argument("--dry-run-topology", action="store_true", help="multi-GPU pre-flight (no timed steps): every rank reports its device UUID, "
+                    "the run FAILS if two ranks share a device although enough devices are visible, the start-up weight broadcast is timed on its own")
+    ap.add_argument("--guard", default="deferred", choices=["sync", "deferred"], help="range-guard check of the timed forwards (engine.guard_check_mode): "
+                    "deferred = no host wait per forward, outputs NaN-poisoned on overflow, every forward checked (guard_poll) before the clock stops")
     args = ap.parse_args()
     sisr = args.task in ("sisr", "train_sisr")
     training = args.task in ("train", "train_sisr")
@@ -275,6 +280,41 @@ def main():
     bcast_bytes = vdist.broadcast_parameters(net, src=0)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    topo = None
+    if world > 1:
+        # Every rank on its OWN device: local_rank % device_count lets a 1-GPU box rehearse N ranks (tests/test_dist_gpu.py), but a real
+        # N-GPU run whose ranks pile up on one device (a launcher that hides devices per rank, a wrong LOCAL_RANK) must not produce a
+        # "scaling" number -- it fails here.  Reference launch pattern: train_denoising_syn.py:280-297 (one process per visible GPU).
+        props = torch.cuda.get_device_properties(dev)
+        mine = (str(getattr(props, "uuid", "")) or f"index{dev.index}", torch.cuda.device_count())
+        seen = [None] * world
+        torch.distributed.all_gather_object(seen, mine)
+        distinct = len({u for u, _ in seen})
+        enough = min(c for _, c in seen) >= world
+        topo = {"ranks": world, "ranks_seen": distinct, "devices_visible_per_rank": [c for _, c in seen], "uuids": [u for u, _ in seen]}
+        if distinct < world and enough:
+            raise SystemExit(f"bench.py: {world} ranks landed on {distinct} distinct devices although every rank sees >= {world} devices "
+                             f"({topo['uuids']}): refusing to report a multi-GPU number (check LOCAL_RANK / HIP_VISIBLE_DEVICES)")
+    if args.dry_run_topology:
+        reps = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            t1 = time.perf_counter()
+            nb = vdist.broadcast_parameters(net, src=0)
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t1) * 1e3)
+        reps = [vdist.max_over_ranks(r, dev) for r in reps]
+        if rank == 0:
+            print(json.dumps({"dry_run_topology": dict(topo or {"ranks": 1, "ranks_seen": 1}, backend=(torch.distributed.get_backend() if world > 1 else None),
+                                                       broadcast_bytes=nb, broadcast_ms=[round(r, 3) for r in reps],
+                                                       broadcast_gb_per_s=round(nb / (min(reps) * 1e-3) / 1e9, 2) if nb else None,
+                                                       first_broadcast_ms_incl_init=round(bcast_ms, 3))}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     # this rank's shard of the global batch (weak scaling: `batch` images per rank), resident in HBM before timing
     a, b = vdist.shard_range(batch * world, world, rank)
@@ -345,9 +385,12 @@ def main():
                 opt.step()
             return (mu_.detach(),)
 
+    if not training:
+        os.environ["VIRNET_GUARD_CHECK"] = args.guard      # (inference forwards; the training step's forward is one autograd Function with its own check)
     with torch.set_grad_enabled(training):
         for _ in range(args.warmup):
             fwd(x)
+        engine.guard_poll()
         timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
         torch.cuda.synchronize()
         barrier()
@@ -360,6 +403,7 @@ def main():
             host_enqueue = time.perf_counter() - t0          # wall time until the K steps are enqueued (the device runs behind; a full
             host_cpu = time.thread_time() - c0               # launch queue blocks here) and the CPU time this thread spent doing it
             torch.cuda.synchronize()
+            engine.guard_poll()                              # deferred guard: every forward of the region has been checked when the clock stops
             barrier()
             elapsed = time.perf_counter() - t0
         ops.set_launch_timer(None)
@@ -396,6 +440,7 @@ def main():
                 for _ in range(n2):
                     mu = fwd(x)[0]
                 torch.cuda.synchronize()
+                engine.guard_poll()
                 el2 = time.perf_counter() - t0
             steady = {"steps": n2, "ms_per_step": round(el2 / n2 * 1e3, 3), "value": round(batch * n2 / el2, 2), "unit": "images/s",
                       "power": ps2.summary()}
@@ -458,8 +503,11 @@ def main():
             # 2*MAC of the direct convolution.  `traffic` is not measured inside a timed run (PMC passes serialise the kernels): it is the
             # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc pass named in `traffic_source`, or null.
             roof = {"bound": "mfma", "achieved": round(algorithmic * factor, 2), "peak": peak, "unit": "TFLOP/s",
+                    "peak_of": ("f16 MFMA dense (v_mfma_f32_32x32x16_f16, 2.5 PFLOP/s nominal)" if peak == F16_MFMA_PEAK_TFLOPS
+                                else "fp32 MFMA dense (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s)"),
                     "frac": round(algorithmic * factor / peak, 4), "frac_algorithmic": round(algorithmic / peak, 4),
                     "traffic": (pmc or {}).get("hbm_bytes_per_launch") if (pmc or {}).get("form", "wino") == form else None,
+                    "traffic_measured_in_run": False,
                     "traffic_source": ("profiles/pmc_latest.json (%s)" % (pmc or {}).get("source", "rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes")
                                        if (pmc or {}).get("form", "wino") == form else None),
                     "kernel": kern, "algorithm": how,
@@ -484,6 +532,7 @@ def main():
         if training:
             gflop_img *= 3.0                  # forward + input-gradient + weight-gradient convs (~3x forward)
         out = {
+            "summary": None,               # (first key on purpose: the driver keeps the head of the line -- filled in below)
             "metric": (f"images/sec (SISR x4 training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if train_sisr else
                        f"images/sec (denoise-syn training step fwd+ELBO+bwd{'+Adam' if args.optimizer else ''}, {args.size}x{args.size}x3)" if training else
                        f"images/sec (SISR x4 fwd, LR {args.size}x{args.size}x3 -> {4 * args.size}x{4 * args.size})" if sisr else
@@ -498,6 +547,7 @@ def main():
                                    + f"U[0,1) images, {batch} per GPU per step (global batch {batch * world}), random-init weights, inputs resident in HBM",
                        "images_per_gpu": batch, "global_batch": batch * world, "image": [3, args.size, args.size],
                        "arithmetic": "fp32 tensors and accumulation; C->C 3x3 convs: " + FORMS[ops.conv_form()][2],
+                       "range_guard": (None if training else f"{args.guard} (engine.guard_check_mode; every timed forward is checked before the clock stops)"),
                        "parallelism": (f"image-sharded x{world}, one weight broadcast ({bcast_bytes} B, {bcast_ms:.1f} ms incl. sync), "
                                        + ("gradient all-reduce per step (fp32 buckets, started inside the backward)" if (training and world > 1)
                                           else "no per-image collective"))},
@@ -518,7 +568,16 @@ def main():
                 "configs[4] train fwd+ELBO+bwd 128x128 x32, bf16 (as written)": run_config(["--task", "train", "--dtype", "bf16", "--steps", "10", "--warmup", "3"]),
                 "configs[4] train, fp32-class arithmetic": run_config(["--task", "train", "--steps", "10", "--warmup", "3"]),
                 "SISR x4 training step, LR 64x64 x16": run_config(["--task", "train_sisr", "--steps", "10", "--warmup", "3"]),
+                # SURVEY 8(d) words the metric as a GLOBAL batch of 256 at every N: the N=1 spot value of that wording (all 256 images on this GPU)
+                "configs[2] global batch 256 on ONE GPU (256x256 x256)": run_config(["--size", "256", "--batch", "256", "--steps", "3", "--warmup", "1"]),
             }
+            cf = list(out["configs"].values())
+            val = lambda d: d.get("value") if isinstance(d, dict) else None        # noqa: E731
+            out["summary"] = {"unit": "images/s, one MI355X", "fwd256_x32": out["value"], "fwd128_x64": val(cf[0]), "sisr_x4_x16": val(cf[1]),
+                              "train_bf16": val(cf[2]), "train_f32class": val(cf[3]), "sisr_train": val(cf[4]), "fwd256_x256_global": val(cf[5]),
+                              "roofline_frac_algorithmic": (roof or {}).get("frac_algorithmic"), "socket_w_mean": (power or {}).get("socket_w_mean")}
+        if out["summary"] is None:
+            out["summary"] = {"unit": out["unit"], "value": out["value"], "n_gpus": world, "roofline_frac_algorithmic": (roof or {}).get("frac_algorithmic")}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define VIRNET_ABI_VERSION 1
+/* 2 (round 5): round 4's additions -- virnet_t_emit / virnet_knet_layer, the emitting and persistent entry points, the convT weight image
+ * that keeps cin when cin % 32 == 0 -- were shipped under version 1; a stale library now fails the version check instead of an
+ * AttributeError / a mis-sized packing. */
+#define VIRNET_ABI_VERSION 2
 
 int virnet_abi_version(void);
 const char* virnet_last_error(void);

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_exit_kernel(const FArgs a) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 2
+      // (runtime chunk count: left rolled -- "#pragma unroll 2" here could not be honoured and warned in every build)
       for (int c = 0; c < nch; ++c) {
         f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
         if (px) {

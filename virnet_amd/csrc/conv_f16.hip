@@ -291,14 +291,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   range_report(a.range_flag, amax);
 
   // ---- epilogue
+  // (lane coordinates re-derived from the hardware lane count through an opaque copy: derived from `tid` they stay live across the K loop,
+  // and at the 256-register budget of the 2 x 3-block tile the allocator parked them -- and with them two B-fragment addresses that are
+  // re-loaded INSIDE the loop behind a vmcnt(0) -- in scratch)
+  int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(lane_e));
+#endif
+  const int l31_e = lane_e & 31, lhi_e = lane_e >> 5;
   if constexpr (EPI == 5) {
-    // planar store: lane = pixel (ox0 + l31), register r = channel (r&3) + 8*(r>>2) + 4*lhi; 32 consecutive x per channel = 128-B runs
+    // planar store: lane = pixel (ox0 + l31_e), register r = channel (r&3) + 8*(r>>2) + 4*lhi_e; 32 consecutive x per channel = 128-B runs
     static_assert(NREP == 1, "planar store is for <= 32 channels");
-    const int px = ox0 + l31;
+    const int px = ox0 + l31_e;
     const size_t plane = (size_t)a.crop_h * a.crop_w;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int n = (r & 3) + 8 * (r >> 2) + 4 * lhi_e;
       if (n >= a.cout) continue;
       const float bias = a.bias ? a.bias[n] : 0.f;
       const float inv = a.inv_scale[n];
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   constexpr int TREG = MREP * 32 * TPIX + (TE ? 128 : 0);   // one slab of one wave; two regions per wave (ping-pong)
   static_assert(4 * 2 * TREG <= 81920, "turn-around regions: two workgroups per CU");   // (launch<> sizes LDS for the larger of the two)
   char* const tbuf = smem + wave * (2 * TREG);
-  const int cq = lane & 7, psub = lane >> 3;
+  const int cq = lane_e & 7, psub = lane_e >> 3;
   // LDS slot of tile pixel p (TE: 16 more bytes per 8 pixels, so that the lanes of one read -- pixels 8 apart -- keep the 36-dword spacing)
   auto pixoff = [](int p) { return p * TPIX + (TE ? (p >> 3) * 16 : 0); };
   unsigned eoff[NIT];
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     for (int mr = 0; mr < MREP; ++mr)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4*>(tbuf + region * TREG + pixoff(mr * 32 + l31) + (8 * g + 4 * lhi) * 4) =
+        *reinterpret_cast<f32x4*>(tbuf + region * TREG + pixoff(mr * 32 + l31_e) + (8 * g + 4 * lhi_e) * 4) =
             f32x4{acc[mr][nr][4 * g], acc[mr][nr][4 * g + 1], acc[mr][nr][4 * g + 2], acc[mr][nr][4 * g + 3]};
   };
   auto mask4 = [&](f32x4 v, f32x4 m) {
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
           const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
 #pragma unroll
           for (int k = 0; k < 4 * NPL; ++k) {
-            const int u = k * 64 + lane;                       // unit: channel u & 31, x-segment (u >> 5) & 3, (row, plane) = u >> 7
+            const int u = k * 64 + lane_e;                       // unit: channel u & 31, x-segment (u >> 5) & 3, (row, plane) = u >> 7
             const int rp = u >> 7, r = rp / NPL, pl = rp - r * NPL;
             const u32x4 v = *reinterpret_cast<const u32x4*>(ub + (u << 4));
             if (oy0 + wave * MREP + r < a.H)

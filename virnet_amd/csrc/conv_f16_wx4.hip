@@ -37,6 +37,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef WX4_LEDGER
+#define WX4_LEDGER 0          // energy-ledger probe builds: see the stage lambda
+#define WX4_LEDGER_OFF_
+#endif
+#ifndef WX4_LEDGER_TILEMOD
+#define WX4_LEDGER_TILEMOD 4
+#endif
+
 namespace {
 using namespace virnet;
 
@@ -74,7 +82,13 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const int q = blockIdx.x >> 3;
   const int qt = fast_div(q, a.mg_ncb);             // (divisions by launch invariants through the host's magic numbers)
   const int cb = __builtin_amdgcn_readfirstlane(q - qt * ncb);
+#if WX4_LEDGER & 64
+  // ledger probe: every XCD walks the same WX4_LEDGER_TILEMOD tiles over and over -- the launch's activations stay in that XCD's L2
+  // (4 tiles) or in the Infinity Cache (32): what HBM and the fabric cost is the difference to the plain build
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt % WX4_LEDGER_TILEMOD);
+#else
   const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt);
+#endif
   if (qt >= a.tiles_per_xcd || tile >= a.ntiles) return;
   const int img = __builtin_amdgcn_readfirstlane(fast_div(tile, a.mg_tpi));
   const int trem = tile - img * (a.ntx * a.nty);
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int lane16 = lane * 16;
   const int jt = wave & 1, rb = wave >> 1;
   const int nch = a.Cin >> 4;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
@@ -155,10 +170,18 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // register is live across stages (the global-load form cost 14 spilled VGPRs at NREP 3: VERDICT r03 weak #7)
   auto rdsft = [&]() {
     if constexpr (PRE == 2) {
-      sm = *reinterpret_cast<const f32x4*>(sft_lds + (ld_so >> 2) + 4 * sq);
-      sa = *reinterpret_cast<const f32x4*>(sft_lds + a.Cin + (ld_so >> 2) + 4 * sq);
-      smh = sft_lds[(ld_so >> 2) + hch];
-      sah = sft_lds[a.Cin + (ld_so >> 2) + hch];
+      // (the thread's offsets into the table are re-derived from lane16 -- live for the weight DMA anyway -- by two opaque VALU ops per
+      // chunk: kept as loop invariants, the table addresses were parked in scratch and re-loaded INSIDE the K loop behind a vmcnt(0))
+      int o4 = 0, o1 = 0;                                   // bytes: 4*sq*4 = lane16 & 48;  hch*4 = (lane16 >> 2) & 63
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("v_and_b32 %0, 48, %1" : "=v"(o4) : "v"(lane16));
+      asm volatile("v_bfe_u32 %0, %1, 2, 6" : "=v"(o1) : "v"(lane16));
+#endif
+      const char* const tb = reinterpret_cast<const char*>(sft_lds) + ld_so;
+      sm = *reinterpret_cast<const f32x4*>(tb + o4);
+      sa = *reinterpret_cast<const f32x4*>(tb + a.Cin * 4 + o4);
+      smh = *reinterpret_cast<const float*>(tb + o1);
+      sah = *reinterpret_cast<const float*>(tb + a.Cin * 4 + o1);
     }
   };
   // pre-activation (AttResUNet.py:54-55) of one loaded pixel quad: lrelu(x * mul + add), zero outside the image AFTER it
@@ -272,7 +295,6 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // no per-piece 64-bit address arithmetic, and a MUBUF instruction, not a FLAT one)
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes), 0,
                                                      (int)(NREP * slab_bytes), 0x00020000);
-  const int lane16 = lane * 16;
   int poff[NDI], pdst[NDI];
 #pragma unroll
   for (int i = 0; i < NDI; ++i) {
@@ -321,6 +343,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #endif
 #pragma unroll
   for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds);
+#if WX4_LEDGER & 8
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) dma_piece(i, 0, w_lds + USTAGE);       // ledger probe NODMA: both buffers hold stage 0 for good
+#endif
   ldp(WX_I(0)); ldp(WX_I(1)); ldp(WX_I(2)); ldp(WX_I(3)); ldp(WX_I(4)); ldp(WX_I(5));
   ldh(WX_I(0)); ldh(WX_I(1)); ldh(WX_I(2)); ldh(WX_I(3)); ldh(WX_I(4)); ldh(WX_I(5));
   ldsft();
@@ -334,6 +360,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   pA(WX_I(1), WX_I(4)); pB(WX_I(1), WX_I(4)); pV(WX_I(1), WX_I(4)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(4));
   hSa(WX_I(0)); hSb(WX_I(0)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(0));
   hSa(WX_I(1)); hSb(WX_I(1)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(1));
+#if WX4_LEDGER & (16 | 256)
+  // ledger probes NOSTAGE / NOVST: the K loop never writes V, so the prologue fills positions {2,5} as well
+  pA(WX_I(0), WX_I(2)); pB(WX_I(0), WX_I(2)); pV(WX_I(0), WX_I(2)); pHi(WX_I(0)); pSub(WX_I(0)); pLo(WX_I(0)); pSt(WX_I(0), WX_I(2));
+  pA(WX_I(1), WX_I(5)); pV(WX_I(1), WX_I(5)); pHi(WX_I(1)); pSub(WX_I(1)); pLo(WX_I(1)); pSt(WX_I(1), WX_I(5));
+  hSa(WX_I(2)); hSb(WX_I(2)); hV(); hHi(); hSub(); hLo(); hSt(WX_I(2));
+#endif
 #ifdef WX4_PROBE_2X
   }
 #endif
@@ -378,24 +410,62 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     const char* const vb = vjt + ji * WX_POS;
     if constexpr (ji == 0) ld_so = cn * 64;
     h8 ah[3 * NREP], al[3 * NREP], bh[3], bl[3];
+    // WX4_LEDGER (tools/probes/joule_ledger.py, profiles/r05_probes.md): probe builds that REMOVE one term of the stage each, so that the
+    // launch's energy (socket W x ms) can be split by difference -- bit 1: no MFMA; 2: A fragments read once per stage (group 0 serves
+    // all); 4: B fragments read once; 8: no weight DMA; 16: no staging arithmetic / V stores; 32: no pixel loads; 64: tiles stay in L2 /
+    // the Infinity Cache (WX4_LEDGER_TILEMOD); 128: no epilogue; 256: staging arithmetic kept, V stores dropped; 512: epilogue without its
+    // global stores; 1024 = the shipped code in a two-kernel build (base).  Never shipped.
     auto rdA = [&](auto gc) {
       constexpr int g = decltype(gc)::value;
+      if constexpr ((WX4_LEDGER & 2) && g != 0) { ah[g] = ah[0]; al[g] = al[0]; return; }
       ah[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 0) * 1024);
       al[g] = *reinterpret_cast<const h8*>(wb + (g * 2 + 1) * 1024);
     };
     auto rdB = [&](auto dc) {
       constexpr int dy = decltype(dc)::value;
+      if constexpr ((WX4_LEDGER & 4) && dy != 0) { bh[dy] = bh[0]; bl[dy] = bl[0]; return; }
       bh[dy] = *reinterpret_cast<const h8*>(vb + boff[dy]);
       bl[dy] = *reinterpret_cast<const h8*>(vb + WX_PLANE + boff[dy]);
     };
-    auto dma = [&](auto ic) { dma_piece(decltype(ic)::value, src_off, wn); };
+    auto dma = [&](auto ic) { if constexpr (!(WX4_LEDGER & 8)) dma_piece(decltype(ic)::value, src_off, wn); };
     auto mfma = [&](auto gc, auto pc_) {
       constexpr int g = decltype(gc)::value, part = decltype(pc_)::value;
       constexpr int dy = g / NREP, nr = g - dy * NREP;
       const h8 wa = part == 0 ? al[g] : ah[g];
       const h8 xv = part == 1 ? bl[dy] : bh[dy];
-      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
+      if constexpr (WX4_LEDGER & 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(wa), "v"(xv));
+#endif
+      } else {
+        acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
+      }
     };
+#if WX4_LEDGER & 16
+    auto pA = [&](auto, auto) {}; auto pB = [&](auto, auto) {}; auto pV = [&](auto, auto) {};
+    auto pHi = [&](auto) {}; auto pSub = [&](auto) {}; auto pLo = [&](auto) {}; auto pSt = [&](auto, auto) {};
+    auto hSa = [&](auto) {}; auto hSb = [&](auto) {}; auto hV = [&]() {}; auto hHi = [&]() {}; auto hSub = [&]() {}; auto hLo = [&]() {};
+    auto hSt = [&](auto) {}; auto pr = [&](auto) {}; auto prHa = [&]() {}; auto prHb = [&]() {}; auto rdsft = [&]() {};
+#elif WX4_LEDGER & 256
+    auto pSt = [&](auto xc, auto) {
+      constexpr int X = decltype(xc)::value;
+      const unsigned q0 = pc[X].h0, q1 = pc[X].h1, q2 = pc[X].l0, q3 = pc[X].l1;     // (asm operands of a generic lambda must be its own locals)
+      (void)q0; (void)q1; (void)q2; (void)q3;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(q0), "v"(q1), "v"(q2), "v"(q3));
+#endif
+    };
+    auto hSt = [&](auto) {
+      const unsigned h = __builtin_bit_cast(unsigned short, hhi), l = __builtin_bit_cast(unsigned short, hlo);
+      (void)h; (void)l;
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::"v"(h), "v"(l));
+#endif
+    };
+#endif
+#if WX4_LEDGER & 32
+    auto ldp = [&](auto) {}; auto ldh = [&](auto) {};
+#endif
 #ifdef VIRNET_F16_TIMING
     long long wx_tprev = (long long)__builtin_amdgcn_s_memtime();
 #define WX_TS(g) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if ((g) < 9) wx_tg[ji][(g)] += t_ - wx_tprev; wx_tprev = t_; } while (0)
@@ -416,6 +486,12 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     // instruction that writes LDS, and while the compiler believes one is pending it turns every wait it inserts into vmcnt(0).
     // Stage 0 leaves its NPX pixel loads in flight (the pieces are older); the last chunk has none, and its stage 2 issued no piece
     // but requested the epilogue's operand tile, which stays in flight.
+#if (WX4_LEDGER & 16) && !(WX4_LEDGER & 32) && defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ji == 1 && !fin) {                                           // ledger NOSTAGE: the pixel loads stay, their values are dropped here
+#pragma unroll
+      for (int b = 0; b < 6; ++b) asm volatile("" ::"v"(d0[b]), "v"(dh[b]));
+    }
+#endif
     constexpr int WAIT_ALL = 0x0070;                                           // vmcnt(0) expcnt(7) lgkmcnt(0)
     constexpr int WAIT_PX = (NPX & 15) | 0x0070 | ((NPX >> 4) << 14);          // vmcnt(NPX) lgkmcnt(0)
     constexpr int WAIT_LDS = 0xC07F;                                           // lgkmcnt(0) only
@@ -440,8 +516,16 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // epilogue reader: thread = (pixel column x of the tile, channel quad cq), items it = row pairs.  One 32-bit byte offset per item
   // serves the operand loads and the stores (buffer instructions; an item outside the image gets an out-of-range offset: loads 0,
   // stores nothing).
-  const int cq = tid & 7, px = (tid >> 3) & 31, prow = tid >> 8;
-  const int te_row = tid >> 5, te_xq = (tid >> 3) & 3;       // TE mapping: tile row 0..15, x-segment 0..3 (items = its 8 pixels)
+  // The epilogue's thread coordinates are re-derived HERE from the wave index (a scalar) and the lane count, through an opaque copy:
+  // derived from `tid` they stay live across the whole K loop, and at the 256-register budget the PRE 2 instantiations parked 3-7 of
+  // them in scratch around the loop.
+  int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(tid_e));
+#endif
+  const int lane_e = tid_e & 63, l31_e = lane_e & 31, lhi_e = lane_e >> 5;
+  const int cq = tid_e & 7, px = (tid_e >> 3) & 31, prow = tid_e >> 8;
+  const int te_row = tid_e >> 5, te_xq = (tid_e >> 3) & 3;       // TE mapping: tile row 0..15, x-segment 0..3 (items = its 8 pixels)
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
 #pragma unroll
@@ -453,6 +537,15 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   stage(nch - 1, WX_I(2), Yes{});
   TSTAMP(2);
   range_report(a.range_flag, amax);
+#if (WX4_LEDGER & (1 | 128)) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int nr = 0; nr < NREP; ++nr) asm volatile("" : "+v"(acc[j][nr]));     // ledger probes: the accumulators stay opaque / alive
+#endif
+#if WX4_LEDGER & 128
+  return;
+#endif
 #ifdef VIRNET_F16_TIMING
   if (a.tlog && (tid & 63) == 0) {
 #pragma unroll
@@ -466,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
   // and pixel k of an x-tile is  k=0: A0 + S   k=1: A1 + 2D   k=2: A2 + 4S   k=3: A1 + 8D + E   (rows of AT).
   char* const xb = smem;
-  const int wblk = (rb * 6 + jt * 3) * WX_XBLK + l31 * 144 + lhi * 16;
+  const int wblk = (rb * 6 + jt * 3) * WX_XBLK + l31_e * 144 + lhi_e * 16;
   auto put_block = [&](int which, const f32x16& m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -566,10 +659,20 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       SB();
       if (EPF && nr + 2 < NREP) load_op1(nr + 2);
       SB();                                          // (the operand requests stay above this slab's stores)
+#if WX4_LEDGER & 512
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {                     // ledger probe NOSTORE: the epilogue without its global stores
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" ::"v"(tv[it]));
+#endif
+      }
+      (void)yrs;
+#else
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
         // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+#endif
       if constexpr (TE) {
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
         f32x4 cs = zero4;
@@ -596,10 +699,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
         {
           char* const tile0 = a.t_out + ((((size_t)img * (a.H + 2) + oy0 + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + 1)) * 512;
           const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
-          const int uch = tid & 31, uxq = (tid >> 5) & 3, upl = (tid >> 7) & 1, urow = tid >> 8;   // unit u = k*512 + tid: row 2k + (tid>>8)
+          const int uch = tid_e & 31, uxq = (tid_e >> 5) & 3, upl = (tid_e >> 7) & 1, urow = tid_e >> 8;   // unit u = k*512 + tid: row 2k + (tid>>8)
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 512 + tid) << 4));
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 512 + tid_e) << 4));
             const int r = 2 * k + urow;
             if (oy0 + r < a.H)
               *reinterpret_cast<u32x4*>(tile0 + r * trow_bytes + (size_t)upl * a.t_nseg * 512 + uxq * 512 + uch * 16) = v;
@@ -612,7 +715,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
             cs[c] += __shfl_xor(cs[c], 16);
             cs[c] += __shfl_xor(cs[c], 32);
           }
-          if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 8 + wave) * 32 + cq * 4) = cs;
+          if (lane_e < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 8 + wave) * 32 + cq * 4) = cs;
         }
       }
       if (nr == 0) TSTAMP(7);
@@ -855,6 +958,12 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
     FArgs kk = k;
     kk.slab_base = slab_base;
     kk.NP = groups * nrep * 32;
+#ifndef WX4_LEDGER_OFF_
+    // ledger probe builds carry the two launch types of the metric's res-blocks only (conv1-type: PRE 1 / plain; conv2-type: residual)
+    if (nrep == 3 && epi == 0 && pre == 1 && !te) return launch_wx4<3, 0, 1>(kk, st);
+    if (nrep == 3 && epi == 1 && pre == 0 && !te) return launch_wx4<3, 1, 0>(kk, st);
+    return virnet::set_error("virnet_conv_wx4: ledger probe build (WX4_LEDGER=%d) has no kernel for nrep=%d epi=%d pre=%d", WX4_LEDGER, nrep, epi, pre);
+#else
     if (te8) return virnet::launch_wx4h_emit(kk, nrep, epi, pre, st);
     if (te) {                                               // emission: the tile form the caller asked for, whatever the launch size
 #define VIRNET_WX4_TE(N_, E_) if (nrep == N_ && epi == E_) return pre == 1 ? launch_wx4<N_, E_, 1, 1>(kk, st) : launch_wx4<N_, E_, 0, 1>(kk, st);
@@ -875,6 +984,7 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
 #undef VIRNET_WX4_CASE
 #undef VIRNET_WX4_EPI
     return virnet::set_error("virnet_conv_wx4: no kernel for nrep=%d", nrep);
+#endif
   };
   // 160 channels (SISR level 1): five slabs in ONE launch of the 8-row form with one workgroup per CU (conv_f16_wx4h.hip, NREP = 5) instead
   // of 3 + 2 slabs in two launches that each stage and transform the pixel tile.  VIRNET_WX4_WIDE=0: the two launches.

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
+  const int lane16 = lane * 16;
   const int jt = wave & 1, rb = wave >> 1;
   const int nch = a.Cin >> 4;
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
@@ -123,10 +124,18 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   // K loop: the chunk's SFT vectors come from the LDS table the prologue filled, read at the point of use (stage 1)
   auto rdsft = [&]() {
     if constexpr (PRE == 2) {
-      sm = *reinterpret_cast<const f32x4*>(sft_lds + (ld_so >> 2) + 4 * sq);
-      sa = *reinterpret_cast<const f32x4*>(sft_lds + a.Cin + (ld_so >> 2) + 4 * sq);
-      smh = sft_lds[(ld_so >> 2) + hch];
-      sah = sft_lds[a.Cin + (ld_so >> 2) + hch];
+      // the thread's offsets into the table are re-derived from lane16 (live for the weight DMA anyway) by two opaque VALU ops per
+      // chunk: as loop invariants the four table addresses were parked in scratch and reloaded INSIDE the K loop behind a vmcnt(0)
+      int o4 = 0, o1 = 0;                                   // bytes: 4*sq*4 = lane16 & 48;  hch*4 = (lane16 >> 2) & 60
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("v_and_b32 %0, 48, %1" : "=v"(o4) : "v"(lane16));
+      asm volatile("v_bfe_u32 %0, %1, 2, 6" : "=v"(o1) : "v"(lane16));
+#endif
+      const char* const tb = reinterpret_cast<const char*>(sft_lds) + ld_so;
+      sm = *reinterpret_cast<const f32x4*>(tb + o4);
+      sa = *reinterpret_cast<const f32x4*>(tb + a.Cin * 4 + o4);
+      smh = *reinterpret_cast<const float*>(tb + o1);
+      sah = *reinterpret_cast<const float*>(tb + a.Cin * 4 + o1);
     }
   };
   auto pr = [&](auto bc) {
@@ -228,7 +237,6 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   const size_t slab_bytes = (size_t)nch * WH_CHUNK_BYTES;
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg + (size_t)(a.slab_base + cb * NREP) * slab_bytes), 0,
                                                      (int)(NREP * slab_bytes), 0x00020000);
-  const int lane16 = lane * 16;
   int poff[NREP], pdst[NREP];
 #pragma unroll
   for (int i = 0; i < NREP; ++i) {
@@ -380,12 +388,19 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
     stage(c, WX_I(1), No{});
     stage(c, WX_I(2), No{});
   }
+  // (thread coordinates re-derived from the scalar wave index + lane count through an opaque copy: derived from `tid` they stay live
+  // across the K loop and the PRE 2 instantiations parked 10-11 of them in scratch -- conv_f16_wx4.hip has the same lines)
+  int tid_e = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(tid_e));
+#endif
   stage(nch - 1, WX_I(0), Yes{});
   stage(nch - 1, WX_I(1), Yes{});
   // epilogue reader: thread = (pixel column x of the tile, channel quad cq), items it = rows.  One 32-bit byte offset per item serves
   // the operand loads and the stores (an item outside the image gets an out-of-range offset: loads 0, stores nothing).
-  const int cq = tid & 7, px = tid >> 3;
-  const int te_row = tid >> 5, te_xq = (tid >> 3) & 3;       // TE mapping: tile row 0..7, x-segment 0..3 (items = its 8 pixels)
+  const int lane_e = tid_e & 63, l31_e = lane_e & 31, lhi_e = lane_e >> 5;
+  const int cq = tid_e & 7, px = tid_e >> 3;
+  const int te_row = tid_e >> 5, te_xq = (tid_e >> 3) & 3;       // TE mapping: tile row 0..7, x-segment 0..3 (items = its 8 pixels)
   const int C = a.cout;
   const size_t img_off = (size_t)img * a.H * a.W * C;
 #pragma unroll
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
   // and pixel k of an x-tile is  k=0: A0 + S   k=1: A1 + 2D   k=2: A2 + 4S   k=3: A1 + 8D + E   (rows of AT).
   char* const xb = smem;
-  const int wblk = (rb * 6 + jt * 3) * WH_XBLK + l31 * 144 + lhi * 16;
+  const int wblk = (rb * 6 + jt * 3) * WH_XBLK + l31_e * 144 + lhi_e * 16;
   auto put_block = [&](int which, const f32x16& m) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -543,10 +558,10 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
         {
           char* const tile0 = a.t_out + ((((size_t)img * (a.H + 2) + oy0 + 1) * a.t_cb + cbg) * a.t_npl * a.t_nseg + ((ox0 >> 3) + 1)) * 512;
           const size_t trow_bytes = (size_t)a.t_cb * a.t_npl * a.t_nseg * 512;
-          const int uch = tid & 31, uxq = (tid >> 5) & 3, upl = tid >> 7;         // unit u = k*256 + tid: row k, plane tid>>7, x-segment, channel
+          const int uch = tid_e & 31, uxq = (tid_e >> 5) & 3, upl = tid_e >> 7;         // unit u = k*256 + tid: row k, plane tid>>7, x-segment, channel
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 256 + tid) << 4));
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xb + ((k * 256 + tid_e) << 4));
             if (oy0 + k < a.H)
               *reinterpret_cast<u32x4*>(tile0 + k * trow_bytes + (size_t)upl * a.t_nseg * 512 + uxq * 512 + uch * 16) = v;
           }
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
             cs[c] += __shfl_xor(cs[c], 16);
             cs[c] += __shfl_xor(cs[c], 32);
           }
-          if ((tid & 63) < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 4 + wave) * 32 + cq * 4) = cs;
+          if (lane_e < 8) *reinterpret_cast<f32x4*>(a.t_col + ((size_t)cbg * a.t_nblk + (size_t)tile * 4 + wave) * 32 + cq * 4) = cs;
         }
       }
       if (nr == 0) TSTAMP(7);

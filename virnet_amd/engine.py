@@ -181,21 +181,99 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
 FP32_FORM = "wino"      # the form of the guard's re-run: Winograd / direct fp32 MFMA kernels, no range limit
 
 
+class RangeOverflowRepaired(RuntimeWarning):
+    """A forward of the deferred guard mode left fp16's range: its outputs were NaN on the device until the repair that this warning
+    announces (the same input repeated with the fp32 kernels, written into the same output tensors)."""
+
+
+_GUARD_WARNING = ("VIRNet HIP path: an activation left fp16's range in a split-fp16 convolution (|x| >= 65504, or >= ~6.5e3 in the "
+                  "Winograd form); the forward was repeated with the fp32 kernels")
+MAX_PENDING = 2         # deferred mode: forwards whose flag copy may still be in flight before the host waits for the oldest
+
+
+def guard_check_mode() -> str:
+    """``VIRNET_GUARD_CHECK``: how the eager forward learns that a split-fp16 kernel raised the range flag.
+
+    * ``sync`` (default; the reference's semantics: what ``forward`` returns is final): one device -> host read at the end of the
+      forward -- it waits for the forward, which a caller that consumes the outputs right away (every reference script) pays anyway.
+    * ``deferred`` (pipelined callers: serving loops, bench.py): NO host wait on the launch path.  The forward ends with
+      ``virnet_poison_on_flag`` on every output (an out-of-range forward is NaN on the device before the host has looked) and an
+      asynchronous copy of the flag into pinned memory + an event; the NEXT guarded forward of the thread (or ``guard_poll()``) looks at
+      the copies that have landed, and for an overflowed forward warns and repeats THAT input with the fp32 kernels into the SAME
+      output tensors -- stream-ordered behind whatever was enqueued meanwhile: loud (NaN) in between, correct afterwards.
+      At most MAX_PENDING forwards stay unchecked; ``guard_poll()`` settles all of them (call it before trusting outputs on the host)."""
+    mode = ops._env("VIRNET_GUARD_CHECK", "sync")
+    if mode not in ("sync", "deferred"):
+        raise ValueError(f"VIRNET_GUARD_CHECK={mode!r}: expected sync or deferred")
+    return mode
+
+
+def _pending_list() -> list:
+    lst = getattr(nat.tls, "guard_pending", None)
+    if lst is None:
+        lst = nat.tls.guard_pending = []
+    return lst
+
+
+def _settle(block: bool, keep: int = 0) -> None:
+    """Look at the deferred forwards of this thread, oldest first: those whose flag copy has landed (all but `keep` of them when
+    `block`) are checked and, if they overflowed, repaired in place."""
+    import warnings
+    pend = _pending_list()
+    while pend:
+        pinned, ev, run, outs, dev = pend[0]
+        if not ev.query():
+            if not block or len(pend) <= keep:
+                return
+            ev.synchronize()
+        pend.pop(0)
+        _PINNED_POOL.append(pinned)
+        if int(pinned[0]):
+            warnings.warn(_GUARD_WARNING + " (deferred check: its outputs were NaN until now)", RangeOverflowRepaired, stacklevel=4)
+            _GUARD_STATS["reruns"] += 1
+            with torch.no_grad(), torch.cuda.device(dev), ops.forward_scope(form=FP32_FORM):
+                res = run()
+            for o, r in zip(outs, res if isinstance(res, tuple) else (res,)):
+                o.copy_(r)
+
+
+_PINNED_POOL: list = []
+
+
+def guard_poll(block: bool = True) -> None:
+    """Deferred guard mode: check (and repair) the calling thread's forwards that have not been looked at yet; with ``block`` the
+    host waits for their flag copies first.  A no-op in sync mode."""
+    _settle(block)
+
+
 def _range_guarded(run, x: Tensor):
     """Run a forward in the default (split-fp16) forms; when a kernel reports an operand outside fp16's range (virnet_set_range_flag)
-    run it again with the fp32 kernels and return that result.  The check reads one int from the device, i.e. it waits for the forward
-    (the caller is about to consume the outputs anyway); it is skipped while a hipGraph is being captured -- graph.GraphedForward does
-    its own check around the replay -- for the fp32 forms and with VIRNET_RANGE_GUARD=0.  The flag is per (device, host thread) and the
-    re-run's form override lives in the thread's forward_scope: nothing process-global is touched."""
+    run it again with the fp32 kernels and return that result.  ``guard_check_mode()`` says when the host looks at the flag: at the end
+    of the forward (sync: one int read, i.e. a wait for the forward) or not on the launch path at all (deferred).  Skipped while a
+    hipGraph is being captured -- graph.GraphedForward does its own check around the replay -- for the fp32 forms and with
+    VIRNET_RANGE_GUARD=0.  The flag is per (device, host thread) and the re-run's form override lives in the thread's forward_scope:
+    nothing process-global is touched."""
     import warnings
     guarded = ops._f16_family() and ops.range_guard_enabled() and not torch.cuda.is_current_stream_capturing()
+    deferred = guarded and guard_check_mode() == "deferred"
     if guarded:
-        ops.range_flag(x.device).zero_()     # (the flag is sticky: whatever raised it before this forward is not this forward's business)
+        _settle(block=False)
+        flag = ops.range_flag(x.device)
+        flag.zero_()                         # (the flag is sticky: whatever raised it before this forward is not this forward's business)
     with ops.forward_scope():                # (environment knobs and the stream handle: read once per forward, not per launch)
         out = run()
-    if guarded and ops.range_overflowed(x.device):
-        warnings.warn("VIRNet HIP path: an activation left fp16's range in a split-fp16 convolution (|x| >= 65504, or >= ~6.5e3 in the "
-                      "Winograd form); the forward was repeated with the fp32 kernels", RuntimeWarning, stacklevel=3)
+    if deferred:
+        outs = out if isinstance(out, tuple) else (out,)
+        for o in outs:
+            ops.poison_on_flag(flag, o)
+        pinned = _PINNED_POOL.pop() if _PINNED_POOL else torch.zeros(1, dtype=torch.int32).pin_memory()
+        pinned.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _pending_list().append((pinned, ev, run, outs, x.device))
+        _settle(block=True, keep=MAX_PENDING)
+    elif guarded and ops.range_overflowed(x.device):
+        warnings.warn(_GUARD_WARNING, RuntimeWarning, stacklevel=3)
         _GUARD_STATS["reruns"] += 1
         with ops.forward_scope(form=FP32_FORM):
             out = run()

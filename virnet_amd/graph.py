@@ -26,6 +26,20 @@ import torch
 from . import ops
 
 
+# Global registration epoch: bumped whenever ANY module registers a parameter or a sub-module (nn.Module.__setattr__ with a Parameter /
+# Module, register_parameter, add_module).  A GraphedForward walks its module tree again only when the epoch has moved; between such
+# events the parameter OBJECTS are the cached ones and the fingerprint is their (storage pointer, version) pairs.
+_EPOCH = [0]
+
+
+def _bump(*_a, **_k):
+    _EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
+torch.nn.modules.module.register_module_module_registration_hook(_bump)
+
+
 class RangeOverflow(RuntimeError):
     """Raised by a ``check="deferred"`` GraphedForward when the PREVIOUS replay staged an operand outside fp16's range."""
 
@@ -40,20 +54,20 @@ class GraphedForward:
         self.fn, self.warmup, self.check = fn, warmup, check
         self._params = params
         self._stamp = None
+        self._plist = None             # (registration epoch, parameter objects) -- see _EPOCH
         self._graphs: Dict[Tuple, Tuple] = {}
         self._pending = None           # (pinned flag copy, event) of the last deferred replay
         self.reruns = 0                # replays repeated with the fp32 kernels (check="sync")
 
-    # ---- parameter fingerprint: sum of versions + the first parameter's storage (a .to() / .cuda() moves all of them)
+    # ---- parameter fingerprint: one hash over every parameter's (storage pointer, version) -- a swapped Parameter, a re-assigned
+    # sub-module, load_state_dict, an optimizer step and .to() all move it (the round-4 form summed the versions and looked
+    # at the first pointer only, so a fresh tensor with the same version in a later slot went unnoticed)
     def _fingerprint(self):
         if self._params is None:
             return None
-        ver, first = 0, None
-        for p in self._params():
-            ver += p._version
-            if first is None:
-                first = (p.data_ptr(), p.device)
-        return ver, first
+        if self._plist is None or self._plist[0] != _EPOCH[0]:
+            self._plist = (_EPOCH[0], list(self._params()))
+        return hash(tuple((p.data_ptr(), p._version) for p in self._plist[1]))
 
     def _guard_flag(self, device) -> Optional[torch.Tensor]:
         if self.check == "off" or not (ops._f16_family() and ops.range_guard_enabled()):

