@@ -480,6 +480,8 @@ def main():
                 return "chsplit_s2 + chsplit + conv_wgrad_f16<S=2> + reduce <ks=%d,s=%d,t=%d>" % k[1:]
             if k[0] == "exit":
                 return "conv_exit<cout=%d>" % k[1]
+            if k[0] == "entry":
+                return "conv_entry<cout=%d>" % k[1]
             if k[0] in ("wino", "f16x3", "f16x3_s2", "f16x3_t", "bf16", "wx4"):
                 return "conv_%s<cout=%d>" % ({"f16x3": "f16", "f16x3_s2": "f16_s2", "f16x3_t": "f16_pw(convT)", "wino": "wino", "bf16": "bf16", "wx4": "wx4"}[k[0]], k[1])
             return "conv_mfma<%d,%d,%d,%d>" % k

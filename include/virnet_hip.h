@@ -236,6 +236,14 @@ int virnet_pack_input(const virnet_pack_desc* d, void* stream);
  * ONE 16-channel chunk (d->cin_pad = 16, d->h x d->w = e->hp x e->wp, plain single-store epilogue) whose staging gathers each pixel's
  * record [image | vector | map | 0] from the NCHW sources of `e` -- the packed tensor never exists (e->out is ignored; c0 + ev + em <= 8). */
 int virnet_conv_f16_entry(const virnet_conv_desc* d, const virnet_pack_desc* e, void* stream);
+/* Round 5: the entries as their own STORE-bound kernel (csrc/conv_entry.hip; same call sites: AttResUNet.py:153-155, DnCNN.py:38).  K is
+ * walked one kernel ROW per MFMA k-step (slot j = dx * cin + ch), the B fragments are gathered from a planar fp32 copy of the input tile in
+ * LDS, every output row leaves as lane-linear 1-KB stores.  cin = c0 + ev + em <= 8, cout a multiple of 32 up to 96, plain epilogue
+ * (exactly one of y_raw / y_act).  Weight image: virnet_entry_weight_floats(cin, n_pad) floats from virnet_pack_entry_weight (OIHW
+ * [cout][cin][3][3] in; n_pad inverse scales first).  Agrees with virnet_conv_f16_entry to fp32 rounding (other summation order). */
+size_t virnet_entry_weight_floats(int cin, int n_pad);
+int virnet_pack_entry_weight(const float* w, int cout, int cin, int n_pad, float* packed, void* stream);
+int virnet_conv_entry(const virnet_conv_desc* d, const virnet_pack_desc* e, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training step: weight / bias gradients and the layout helpers of the input-gradient convs.

@@ -448,6 +448,43 @@ def test_winograd_randomised_sweep_against_direct_kernel(monkeypatch):
     assert worst > 0.0            # the two algorithms are different roundings of the same sums
 
 
+ENTRY_CASES = [
+    (2, 3, 45, 70, 1, 48, 72, 0, 1, 1, True, 96, False),      # denoiser head: image + sqrt(sigma) map, reflect pad on both axes
+    (1, 3, 64, 64, 1, 64, 64, 0, 0, 1, False, 64, True),      # DnCNN.conv1: image only, activated store
+    (3, 3, 16, 20, 4, 64, 80, 4, 0, 1, False, 96, False),     # SISR head: nearest x4, kernel / noise vector (7 channels: two k-steps per row)
+    (2, 3, 9, 7, 3, 28, 24, 3, 1, 3, True, 96, False),        # SISR with a per-pixel variance map (nearest x3) + vector, padded
+    (5, 1, 33, 31, 2, 68, 64, 0, 2, 2, False, 32, True),      # one image channel, two map channels
+    (1, 3, 7, 5, 1, 8, 8, 0, 1, 1, True, 96, False),          # a single partial tile
+    (2, 3, 40, 100, 1, 40, 100, 0, 1, 1, True, 96, False),    # width not a multiple of the tile: the last tile's rows are cut
+]
+
+
+@pytest.mark.parametrize("n,c0,h,w,sf,hp,wp,ev,em,msf,msqrt,cout,act", ENTRY_CASES)
+def test_conv_entry_kernel_vs_oracle_and_two_launch_path(n, c0, h, w, sf, hp, wp, ev, em, msf, msqrt, cout, act, monkeypatch):
+    """virnet_conv_entry (csrc/conv_entry.hip, round 5: the store-bound entry kernel, K walked one kernel row per MFMA k-step) against an fp64
+    convolution of the packed record (AttResUNet.py:153-155 / DnCNN.py:38 on util_net.py:20-25's padding, VIRNet.py:83,94,44) and
+    against the two-launch path: the same split-fp16 products in another summation order -- fp32 rounding apart, nothing else."""
+    cp = make_conv(c0 + ev + em, cout, seed=61).cuda()
+    x = rnd(n, c0, h, w, seed=62, lo=0.0, hi=1.0).cuda()
+    vec = rnd(n, ev, seed=63).cuda() if ev else None
+    mp = rnd(n, em, h * sf // msf, w * sf // msf, seed=64, lo=0.01, hi=2.0).cuda() if em else None
+    kw = dict(sf=sf, vec=vec, map_=mp, map_sf=msf, map_sqrt=msqrt, want_act=act, slope=0.25)
+    assert cp.packed().entry is not None
+    got = ops.conv_entry(x, cp.packed(), hp, wp, **kw)
+    assert tuple(got.shape) == (n, hp, wp, cout)
+    monkeypatch.setenv("VIRNET_ENTRY_FUSED", "0")
+    two = ops.conv_entry(x, cp.packed(), hp, wp, **kw)
+    rec = ops.pack_input(x, hp, wp, sf=sf, vec=vec, map_=mp, map_sf=msf, map_sqrt=msqrt)          # NHWC [n][hp][wp][16]
+    ref = torch.nn.functional.conv2d(rec[..., :c0 + ev + em].permute(0, 3, 1, 2).cpu().double(), cp.weight.detach().cpu().double(),
+                                     cp.bias.detach().cpu().double(), padding=1)
+    if act:
+        ref = torch.nn.functional.leaky_relu(ref, 0.25)
+    ref = ref.permute(0, 2, 3, 1).float()
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxerr(got.cpu(), ref) <= 2e-6 * scale, maxerr(got.cpu(), ref)
+    assert maxerr(got.cpu(), two.cpu()) <= 2e-6 * scale
+
+
 @pytest.mark.parametrize("n,c0,h,w,sf,hp,wp,ev,em,msf,msqrt,cout,act", [
     (2, 3, 45, 70, 1, 48, 72, 0, 1, 1, True, 96, False),      # denoiser head: image + sqrt(sigma) map, reflect pad on both axes
     (1, 3, 64, 64, 1, 64, 64, 0, 0, 1, False, 64, True),      # DnCNN.conv1: image only, activated store
@@ -464,6 +501,7 @@ def test_conv_entry_is_bitwise_pack_plus_conv(n, c0, h, w, sf, hp, wp, ev, em, m
     vec = rnd(n, ev, seed=63).cuda() if ev else None
     mp = rnd(n, em, h * sf // msf, w * sf // msf, seed=64, lo=0.01, hi=2.0).cuda() if em else None
     kw = dict(sf=sf, vec=vec, map_=mp, map_sf=msf, map_sqrt=msqrt, want_act=act, slope=0.25)
+    monkeypatch.setenv("VIRNET_ENTRY_FORM", "f16")            # (round 4's fused form; the default since round 5 is csrc/conv_entry.hip: test above)
     fused = ops.conv_entry(x, cp.packed(), hp, wp, **kw)
     monkeypatch.setenv("VIRNET_ENTRY_FUSED", "0")
     two = ops.conv_entry(x, cp.packed(), hp, wp, **kw)

@@ -117,6 +117,9 @@ SYMBOLS = [
     ("virnet_pack_f16_convt_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_pack_input", C.c_int, [C.POINTER(PackDesc), C.c_void_p]),
     ("virnet_conv_f16_entry", C.c_int, [C.POINTER(ConvDesc), C.POINTER(PackDesc), C.c_void_p]),
+    ("virnet_entry_weight_floats", C.c_size_t, [C.c_int, C.c_int]),
+    ("virnet_pack_entry_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    ("virnet_conv_entry", C.c_int, [C.POINTER(ConvDesc), C.POINTER(PackDesc), C.c_void_p]),
     ("virnet_thin_weight_floats", C.c_size_t, [C.c_int]),
     ("virnet_pack_thin_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv3x3_thin", C.c_int, [C.POINTER(ThinDesc), C.c_void_p]),

@@ -34,6 +34,7 @@ class PackedWeight:
     bf16: Optional[Tensor] = None   # bf16-operand image (virnet_pack_bf16_weight) of a C->C stride-1 3x3 layer (form "bf16" only)
     wx4: Optional[Tensor] = None    # Winograd F(4,3)-along-x split-fp16 image (virnet_pack_wx4_weight) of a C->C stride-1 3x3 layer (form "wx4")
     exit: Optional[Tensor] = None   # taps-as-rows split-fp16 image (virnet_pack_exit_weight) of a 3x3 layer with <= 3 output channels
+    entry: Optional[Tensor] = None  # kernel-row-per-k-step split-fp16 image (virnet_pack_entry_weight) of a 3x3 layer with <= 8 input channels (csrc/conv_entry.hip)
     s2: Optional["PackedWeight"] = None   # dgrad packing of the 2x2 transposed conv: the same GEMM as a 3x3 stride-2 conv (convt_dgrad)
 
 
@@ -405,6 +406,9 @@ def pack_weight(weight: Tensor, bias: Optional[Tensor], *, transposed: bool = Fa
             # every stride-1 3x3 layer: the C->C convs, the few-input-channel entry convs (HBM-bound: one 16-channel chunk) and, through
             # the planar store, the few-output-channel exits
             pw.f16 = pack_f16_weight(weight)
+            if cin <= 8 and cout % 32 == 0 and cout <= 96:        # head / DnCNN.conv1: csrc/conv_entry.hip
+                pw.entry = torch.empty(lib.virnet_entry_weight_floats(cin, cout), dtype=torch.float32, device=weight.device)
+                nat.check(lib.virnet_pack_entry_weight(nat.ptr(weight), cout, cin, cout, nat.ptr(pw.entry), nat.stream_handle()), "pack_entry_weight")
             if cout * 9 <= 32:                                    # tail / conv_last / KNet tail: csrc/conv_exit.hip
                 pw.exit = torch.empty(lib.virnet_exit_weight_floats(plan.cin_pad), dtype=torch.float32, device=weight.device)
                 nat.check(lib.virnet_pack_exit_weight(nat.ptr(weight), cout, cin, plan.cin_pad, nat.ptr(pw.exit), nat.stream_handle()), "pack_exit_weight")
@@ -769,7 +773,10 @@ def conv_entry(x: Tensor, pw: PackedWeight, hp: int, wp: int, *, sf: int = 1, ve
         if t is not None:
             _dev_check(t, nm)
     out = torch.empty((n, hp, wp, pw.cout), dtype=torch.float32, device=x.device)
-    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.f16), bias=nat.ptr(pw.bias), res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0,
+    # the store-bound entry kernel (csrc/conv_entry.hip) when its weight image exists; VIRNET_ENTRY_FORM=f16 keeps round 4's conv_f16 ENT form
+    # (bitwise = pack_input + conv_f16; the two agree to fp32 rounding)
+    use_entry = pw.entry is not None and c0 + ev + em == pw.cin_real and _env("VIRNET_ENTRY_FORM", "rows") != "f16"
+    d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.entry if use_entry else pw.f16), bias=nat.ptr(pw.bias), res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0,
                      y_raw=0 if want_act else nat.ptr(out), y_act=nat.ptr(out) if want_act else 0, n=n, h=hp, w=wp, cin_pad=16, cout=pw.cout,
                      n_pad=pw.n_pad, nrep=pw.nrep, ks=3, stride=1, epi=nat.EPI_NHWC, nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=0,
                      in_slope=0.0, slope=slope, clamp_lo=0.0, clamp_hi=0.0)
@@ -777,14 +784,15 @@ def conv_entry(x: Tensor, pw: PackedWeight, hp: int, wp: int, *, sf: int = 1, ve
                      msf=map_sf, map_sqrt=int(map_sqrt), hp=hp, wp=wp, zero_pad=0)
     lib = nat.load()
     flops = 2.0 * n * hp * wp * pw.cin_real * pw.cout * 9
+    fn, what = (lib.virnet_conv_entry, "conv_entry") if use_entry else (lib.virnet_conv_f16_entry, "conv_f16_entry")
     if _TIMER is None:
-        nat.check(lib.virnet_conv_f16_entry(C.byref(d), C.byref(e), nat.stream_handle()), "conv_f16_entry")
+        nat.check(fn(C.byref(d), C.byref(e), nat.stream_handle()), what)
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        nat.check(lib.virnet_conv_f16_entry(C.byref(d), C.byref(e), nat.stream_handle()), "conv_f16_entry")
+        nat.check(fn(C.byref(d), C.byref(e), nat.stream_handle()), what)
         e1.record()
-        _TIMER.records.append((("f16x3", pw.cout), flops, e0, e1))
+        _TIMER.records.append(((("entry" if use_entry else "f16x3"), pw.cout), flops, e0, e1))
     return out
 
 
