@@ -190,7 +190,9 @@ def test_outputs_are_fresh_and_module_api(manifest):
         net.eval()
     assert torch.equal(mu_b, keep) and not mu_b.requires_grad
     mu_c, _ = net(x)          # grad mode on: same numbers, now recorded for backward (train_denoising_syn.py:176)
-    assert torch.equal(mu_c, keep) and mu_c.requires_grad
+    # (fp32 rounding apart: since round 5 the inference forward's entry convs run on csrc/conv_entry.hip, which sums the 3x3xC products in
+    # another order than the training step's pack_input + conv_f16 pair; both are held to the oracle separately)
+    assert float((mu_c - keep).abs().max()) <= 2e-5 * max(1.0, float(keep.abs().max())) and mu_c.requires_grad
     with pytest.raises(ValueError, match="channels"):
         net(torch.zeros(1, 1, 32, 32, device="cuda"))
 

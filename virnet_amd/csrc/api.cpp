@@ -1,6 +1,7 @@
 // api.cpp -- process-level pieces of the C ABI (version, error slot, device probe).
 #include "common.h"
-namespace virnet { int* range_flag_ptr(); }
+#include <cstdlib>
+namespace virnet { int* range_flag_ptr(); int store_nt_for(size_t bytes); }
 #include "../../include/virnet_hip.h"
 
 namespace virnet {
@@ -26,6 +27,15 @@ int* range_flag_ptr() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return nullptr;
   return g_range_flag[dev];
+}
+
+int store_nt_for(size_t bytes) {
+  static long limit = -1;
+  if (limit < 0) {
+    const char* e = getenv("VIRNET_NT_STORE_MB");
+    limit = e ? atol(e) : 128;
+  }
+  return limit > 0 && bytes > (size_t)limit * 1048576u;
 }
 
 }  // namespace virnet

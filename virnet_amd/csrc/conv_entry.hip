@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
 #else
           const bool keep = u < valid;
 #endif
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, keep ? rowoff + (unsigned)u * 16u : 0x80000000u, 0, 0);
+          if (a.store_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, keep ? rowoff + (unsigned)u * 16u : 0x80000000u, 0, 2);
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, keep ? rowoff + (unsigned)u * 16u : 0x80000000u, 0, 0);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the reads have returned before the next row overwrites the region
@@ -316,7 +317,9 @@ int launch_entry(FArgs k, int nchan, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
   }
   const char* const env = getenv("VIRNET_ENTRY_WGS_PER_CU");
-  const int per_cu = env && atoi(env) > 0 ? atoi(env) : 2;
+  int occ = 0;        // workgroups that really are co-resident on a CU (registers and this launch's LDS)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, (size_t)lds) != hipSuccess || occ <= 0) occ = 1;
+  const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(3, occ);
   const int wgs_per_xcd = std::max(1, std::min(k.tiles_per_xcd, per_cu * n_cu / 8));
   const virnet_pack_desc& e = k.ent;
   EntrySrc src{};
@@ -370,6 +373,7 @@ extern "C" int virnet_conv_entry(const virnet_conv_desc* d, const virnet_pack_de
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = nchan; k.cout = d->cout; k.NP = d->n_pad; k.slope = d->slope;
   k.ent = *e;
   k.range_flag = virnet::range_flag_ptr();
+  k.store_nt = virnet::store_nt_for((size_t)d->n * d->h * d->w * d->cout * 4);
   k.nty = (d->h + EN_TH - 1) / EN_TH;
   k.ntx = (d->w + EN_TW - 1) / EN_TW;
   k.ntiles = k.N * k.nty * k.ntx;

@@ -44,6 +44,8 @@ struct FArgs {
   int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
   float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
   long long* tlog;
+  int store_nt;            // 1: the stored tensor is larger than the Infinity Cache and is read back only after it has left it -- its stores carry the
+                           // non-temporal policy bit (measured in J per launch, profiles/r05_probes.md 6: -1.5 % on a conv1-type 96-channel launch)
   int* range_flag;         // sticky device flag (virnet_set_range_flag) set when a staged operand leaves fp16's range, or NULL
   // T emission (training step; kernels instantiated with TE = 1): besides the NHWC tensor the epilogue writes the channel-major
   // fp16 hi|lo (or bf16) image wgrad_f16.hip contracts over -- T[n][H+2][t_cb][t_npl][t_nseg][32 ch][8 px], pixel x at index x + 8 --
@@ -176,6 +178,8 @@ __device__ __forceinline__ b8 to_bf16x8(const f32x4& a, const f32x4& b) {
 
 // the flag registered for the current device (api.cpp), or NULL
 int* range_flag_ptr();
+// store policy of an output of `bytes` bytes: non-temporal above VIRNET_NT_STORE_MB (default 128: the 96- and 192-channel levels of a 32 x 256^2 step; 0 = never)
+int store_nt_for(size_t bytes);
 
 // stride-2 form (conv_f16_s2.hip): `k` filled as for the stride-1 launch, H/W = INPUT size, OH/OW = output size; nb = 32-channel slabs
 int launch_f16_s2(FArgs k, int nb, hipStream_t st);

@@ -41,6 +41,12 @@
 #define WX4_LEDGER 0          // energy-ledger probe builds: see the stage lambda
 #define WX4_LEDGER_OFF_
 #endif
+#ifndef WX4_STORE_AUX
+#define WX4_STORE_AUX 0       // cache-policy bits of the epilogue's stores (probe builds: 1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef WX4_LOAD_AUX
+#define WX4_LOAD_AUX 0        // ... of the pixel loads
+#endif
 #ifndef WX4_LEDGER_TILEMOD
 #define WX4_LEDGER_TILEMOD 4
 #endif
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   constexpr unsigned OOB = 0x80000000u;
   auto ldp = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
-    d0[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : OOB, ld_so, 0));
+    d0[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ((it0.inb >> b) & 1u) ? it0.voff + b * pxb : OOB, ld_so, WX4_LOAD_AUX));
   };
   auto ldh = [&](auto bc) {
     constexpr int b = decltype(bc)::value;
@@ -668,10 +674,15 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
       }
       (void)yrs;
 #else
+      // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2; the cache policy is an
+      // immediate too: two copies of the eight stores behind a uniform branch)
+      if (a.store_nt) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        // (slab offset in the instruction's immediate, not in soffset: conv_f16.hip, store-data hazard of hipcc 7.2)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+        for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 2);
+      } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, WX4_STORE_AUX);
+      }
 #endif
       if constexpr (TE) {
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
@@ -895,6 +906,7 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
 #endif
   hipStream_t st = static_cast<hipStream_t>(stream);
   k.range_flag = virnet::range_flag_ptr();
+  k.store_nt = virnet::store_nt_for((size_t)d->n * d->h * d->w * d->cout * 4);
 #ifdef WX4_PROBE_2X
   k.nchw_op = getenv("WX4_PROBE_REPS") ? atoi(getenv("WX4_PROBE_REPS")) : 1;
 #endif

@@ -514,9 +514,13 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
       SB();
       if (EPF && nr + 2 < NREP) load_op1(nr + 2);
       SB();
+      if (a.store_nt) {                                    // (non-temporal stores for tensors larger than the Infinity Cache: conv_f16_wx4.hip)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+        for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 2);
+      } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, tv[it]), yrs, yoff[it] + nr * 128, 0, 0);
+      }
       if constexpr (TE) {
         const int cbg = (nbase >> 5) + nr;                  // 32-channel block of the stored tensor
 #ifdef VIRNET_TE_DIRECT
