@@ -693,6 +693,7 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
     t.bias = d->bias; t.res = d->res; t.y_raw = d->y_raw; t.y_act = d->y_act;
     t.N = d->n; t.H = d->h; t.W = d->w; t.cout = d->cout; t.in_act = d->in_act; t.in_slope = d->in_slope; t.slope = d->slope;
     t.range_flag = virnet::range_flag_ptr();
+    t.store_nt = virnet::store_nt_for((size_t)d->n * d->h * d->w * 4 * d->cout * 4);
     return virnet::launch_f16_convt(t, d->cin_pad, static_cast<hipStream_t>(stream));
   }
   VIRNET_REQUIRE(d->ks == 3 && ((d->stride == 1 && (d->epi == VIRNET_EPI_NHWC || d->epi == VIRNET_EPI_NCHW)) || (d->stride == 2 && d->epi == VIRNET_EPI_NHWC)),
@@ -734,6 +735,7 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
     VIRNET_REQUIRE(!d->res && !d->mask && !d->mul && !d->in_mul && !(d->y_raw && d->y_act),
                    "virnet_conv_f16: the stride-2 form has the bias / single-store epilogue only");
     k.OH = d->h / 2; k.OW = d->w / 2;
+    k.store_nt = virnet::store_nt_for((size_t)d->n * k.OH * k.OW * d->n_pad * 4);
     return virnet::launch_f16_s2(k, d->n_pad / 32, st);
   }
   const int nb = d->n_pad / 32;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256 * NG, KS == 2 ? 2 * NG : NG) void conv_f16_pw_k
     if (RV_ALL || nr == 0) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        rv[RV_ALL ? nr : 0][it] = has_res ? *reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[RV_ALL ? nr : 0][it] = has_res ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr])) : f32x4{0.f, 0.f, 0.f, 0.f};      // (nt: a bridge byte is read once)
     }
   }
   auto turn_in = [&](int nr, int region) {
@@ -271,11 +271,17 @@ __global__ __launch_bounds__(256 * NG, KS == 2 ? 2 * NG : NG) void conv_f16_pw_k
     if (!RV_ALL && nr + 1 < NREP) {                      // next slab's bridge values: requested before this slab's stores (one vmcnt)
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        rv[0][it] = has_res ? *reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr + 1]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        rv[0][it] = has_res ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.res + pbase[it] + eo[nr + 1])) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (a.store_nt) {                                    // (tensors larger than the Infinity Cache: non-temporal stores, conv_f16_wx4.hip)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      if (pok[it]) *reinterpret_cast<f32x4*>(y + pbase[it] + eo[nr]) = ov[it];
+      for (int it = 0; it < NIT; ++it)
+        if (pok[it]) __builtin_nontemporal_store(ov[it], reinterpret_cast<f32x4*>(y + pbase[it] + eo[nr]));
+    } else {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (pok[it]) *reinterpret_cast<f32x4*>(y + pbase[it] + eo[nr]) = ov[it];
+    }
   }
 }
 

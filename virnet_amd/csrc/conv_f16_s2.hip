@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const f32x4 v = lrelu4(tv[it] * inv4[nr] + b4, slope_eff);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);   // (immediate, not soffset: conv_f16.hip)
+      // (immediate, not soffset: conv_f16.hip; non-temporal for tensors larger than the Infinity Cache: conv_f16_wx4.hip)
+      if (a.store_nt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, yoff[it] + nr * 128, 0, 0);
     }
   }
 }

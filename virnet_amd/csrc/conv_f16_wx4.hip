@@ -44,6 +44,9 @@
 #ifndef WX4_STORE_AUX
 #define WX4_STORE_AUX 0       // cache-policy bits of the epilogue's stores (probe builds: 1 sc0, 2 nt, 16 sc1)
 #endif
+#ifndef WX4_RES_AUX
+#define WX4_RES_AUX 2         // ... of the epilogue's residual / mask tile loads: nt -- every byte is read exactly once (-0.7...1.0 % of J per conv2-type launch)
+#endif
 #ifndef WX4_LOAD_AUX
 #define WX4_LOAD_AUX 0        // ... of the pixel loads
 #endif
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   decltype(__builtin_amdgcn_make_buffer_rsrc((float*)nullptr, 0, 0, 0)) op1rs;
   auto epf = [&](auto ic) {
     constexpr int it = decltype(ic)::value;
-    if constexpr (EPF) op1[0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it], 0, 0));
+    if constexpr (EPF) op1[0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it], 0, WX4_RES_AUX));
   };
   auto stage = [&](int c, auto jic, auto finc) {
     constexpr int ji = decltype(jic)::value;
@@ -626,7 +629,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     auto load_op1 = [&](int nr) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, 0));
+        op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, WX4_RES_AUX));
     };
     const auto yrs = __builtin_amdgcn_make_buffer_rsrc(y, 0, a.H * a.W * C * 4, 0x00020000);
 #ifdef WX4_PROBE_2X

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   decltype(__builtin_amdgcn_make_buffer_rsrc((float*)nullptr, 0, 0, 0)) op1rs;
   auto epf = [&](auto ic) {
     constexpr int it = decltype(ic)::value;
-    if constexpr (EPF) op1[0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it], 0, 0));
+    if constexpr (EPF) op1[0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it], 0, 2));        // (nt: a residual / mask byte is read exactly once -- conv_f16_wx4.hip, WX4_RES_AUX)
   };
   auto stage = [&](int c, auto jic, auto finc) {
     constexpr int ji = decltype(jic)::value;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
     auto load_op1 = [&](int nr) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, 0));
+        op1[EPF ? nr : 0][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(op1rs, yoff[it] + nr * 128, 0, 2));
     };
     xwrite(0);
     if (EPF && NREP > 1) load_op1(1);
