@@ -44,6 +44,7 @@ struct FArgs {
   int nchw_op, crop_h, crop_w, res_sf;      // EPI 5 (planar store)
   float in_slope, mask_slope, slope, clamp_lo, clamp_hi;
   long long* tlog;
+  int rev;                 // 1: tiles are walked in reverse order (conv_wx4 / conv_wx4h: alternating launches, see virnet_conv_wx4)
   int store_nt;            // 1: the stored tensor is larger than the Infinity Cache and is read back only after it has left it -- its stores carry the
                            // non-temporal policy bit (measured in J per launch, profiles/r05_probes.md 6: -1.5 % on a conv1-type 96-channel launch)
   int* range_flag;         // sticky device flag (virnet_set_range_flag) set when a staged operand leaves fp16's range, or NULL

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // (4 tiles) or in the Infinity Cache (32): what HBM and the fabric cost is the difference to the plain build
   const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt % WX4_LEDGER_TILEMOD);
 #else
-  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt);
+  // (a.rev: the XCD walks its tile range backwards -- consecutive launches alternate, so a launch starts on the tiles its producer wrote last)
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + (a.rev ? a.tiles_per_xcd - 1 - qt : qt));
 #endif
   if (qt >= a.tiles_per_xcd || tile >= a.ntiles) return;
   const int img = __builtin_amdgcn_readfirstlane(fast_div(tile, a.mg_tpi));
@@ -910,6 +911,13 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
   hipStream_t st = static_cast<hipStream_t>(stream);
   k.range_flag = virnet::range_flag_ptr();
   k.store_nt = virnet::store_nt_for((size_t)d->n * d->h * d->w * d->cout * 4);
+  {
+    // VIRNET_WX4_ALT=1 (probe): consecutive Winograd launches of a host thread walk their tiles in opposite directions, so that a conv starts
+    // on the part of its input that its producer wrote last (still in the Infinity Cache)
+    static thread_local int parity = 0;
+    static const bool alt = getenv("VIRNET_WX4_ALT") && getenv("VIRNET_WX4_ALT")[0] == '1';
+    k.rev = alt ? (parity ^= 1) : 0;
+  }
 #ifdef WX4_PROBE_2X
   k.nchw_op = getenv("WX4_PROBE_REPS") ? atoi(getenv("WX4_PROBE_REPS")) : 1;
 #endif

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256, NREP > 3 ? 1 : 2) void conv_wx4h_kernel(const 
   const int q = blockIdx.x >> 3;
   const int qt = fast_div(q, a.mg_ncb);
   const int cb = __builtin_amdgcn_readfirstlane(q - qt * ncb);
-  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + qt);
+  // (a.rev: the XCD walks its tile range backwards -- consecutive launches alternate, so a launch starts on the tiles its producer wrote last)
+  const int tile = __builtin_amdgcn_readfirstlane(xcd * a.tiles_per_xcd + (a.rev ? a.tiles_per_xcd - 1 - qt : qt));
   if (qt >= a.tiles_per_xcd || tile >= a.ntiles) return;
   const int img = __builtin_amdgcn_readfirstlane(fast_div(tile, a.mg_tpi));
   const int trem = tile - img * (a.ntx * a.nty);
