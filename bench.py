@@ -215,8 +215,9 @@ def load_pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps before the timed region (default 10: the socket needs ~0.2 s of load to settle at its cap / clock -- with 3 the first timed steps still run on the ramp: 1 541 vs 1 571 img/s in one process, profiles/r05_bench_default_line.json)")
     ap.add_argument("--size", type=int, default=256, help="image height=width")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32 @256, 64 @128)")
     ap.add_argument("--task", default="denoise", choices=["denoise", "sisr", "train", "train_sisr"],
