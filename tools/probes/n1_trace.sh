@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=/root/repo
+R=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf $R/gpurun_out/prof_n1; mkdir -p $R/gpurun_out/prof_n1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_n1 -o t --output-format csv -- python $R/tools/probes/n1_trace.py > $R/gpurun_out/prof_n1/log.txt 2>&1
 f=$(find $R/gpurun_out/prof_n1 -name "*kernel_trace.csv" | head -1)
