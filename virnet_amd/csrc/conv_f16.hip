@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
   constexpr int PPT = (NPIECE + 255) / 256;
   static_assert(PPT >= 2 && PPT <= 3, "one staged piece per tap group; surplus threads redo piece k-1");
   constexpr int PLANE = NPIX * 32, XB = 2 * PLANE;
-  constexpr int WGRP = 3 * NREP * 2048;            // one tap group (three taps) of weight fragments
-  constexpr int NDMA = 3 * NREP * 2;               // ... in 1-KB DMA pieces
+  // CS ("chunk stages", the single-slab forms NREP = 1 of under-filled launches): a weight stage is a whole CHUNK (nine taps)
+  // and the workgroup meets at a barrier once per chunk instead of once per tap group.  With 9 MFMAs per wave between two barriers the
+  // group was 1 250 cycles of barrier + exposed LDS latency for 288 cycles of matrix work (profiles/r05_probes.md 9: removing the weight
+  // DMA and the pixel loads altogether changed 30.8 us into 28.2); same LDS as the three-slab form's two tap-group stages.
+  constexpr bool CS = NREP == 1 && !ENT;
+  constexpr int WGRP = (CS ? 9 : 3) * NREP * 2048;  // one weight stage: a tap group (three taps) of fragments, or the chunk's nine
+  constexpr int NDMA = (CS ? 9 : 3) * NREP * 2;     // ... in 1-KB DMA pieces
   constexpr int NR = MREP + 2;                     // input rows per wave and kernel column
   constexpr int NB = 32 * NREP;
 
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       const int qd = BF ? 2 * (i * 4 + wave) : i * 4 + wave;        // (bf16 variant: the hi pieces only)
       if (qd < NDMA) {
         const int tg = qd / (NREP * 2), rem = qd - tg * (NREP * 2);
-        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * 3 + tg) * 2 + (rem & 1)) * 1024);
+        lds_dma16(wrs, wb + qd * 1024, lane16w, (rem >> 1) * (int)slab_bytes + ((stage * (CS ? 9 : 3) + tg) * 2 + (rem & 1)) * 1024);     // (CS: stage = chunk)
       }
     }
   };
@@ -210,9 +215,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
     const int stage = c * 3 + g;
     const char* const xb = x_lds + P * XB;
     char* const xn = x_lds + (P ^ 1) * XB;
-    const char* const wb = w_lds + ((P + g) & 1) * WGRP;
-    char* const wn = w_lds + ((P + g + 1) & 1) * WGRP;
-    if (stage + 1 < nstages) dma_group(stage + 1, wn);
+    const char* const wb = CS ? w_lds + P * WGRP + g * (3 * NREP * 2048) : w_lds + ((P + g) & 1) * WGRP;
+    char* const wn = CS ? w_lds + (P ^ 1) * WGRP : w_lds + ((P + g + 1) & 1) * WGRP;
+    if constexpr (CS) {
+      if (g == 0 && c + 1 < nch) dma_group(c + 1, wn);             // the next chunk's nine taps: three tap groups of time to land
+    } else {
+      if (stage + 1 < nstages) dma_group(stage + 1, wn);
+    }
     // one piece of the next chunk's pixels (the last chunk re-stages itself into the idle buffer: no branch in the tap code)
     const int cn = min(c + 1, nch - 1);
     f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
       }
     }
     SB();
-    __syncthreads();
+    if constexpr (!CS || g == 2) __syncthreads();
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const FArgs a) {
 template <int MREP, int NREP, int EPI, int BF = 0, int TE = 0, int ENT = 0>
 int launch(FArgs k, hipStream_t st) {
   constexpr int TH = 4 * MREP;
-  constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (3 * NREP * 2048);       // K loop: pixel tiles + weight stages
+  constexpr int LDS_K = 2 * (2 * (TH + 2) * 34 * 32) + 2 * (((NREP == 1 && !ENT) ? 9 : 3) * NREP * 2048);       // K loop: pixel tiles + weight stages (CS: whole chunks)
   constexpr int LDS_E = (EPI == 5) ? 0 : 4 * 2 * (MREP * 32 * 144 + (TE ? 128 : 0));   // epilogue: two turn-around regions per wave
   constexpr int LDS = LDS_K > LDS_E ? LDS_K : LDS_E;
   static unsigned long long attr_done = 0;
