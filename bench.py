@@ -12,7 +12,12 @@ collective is the start-up weight broadcast (RCCL), nothing is exchanged per ima
 ``--gpus N`` without a torchrun environment re-executes itself through ``torch.distributed.run`` (N ranks on this node), so the
 plain command works as well as the torchrun one.
 
-Rank 0 prints ONE JSON line; besides the contract fields it carries
+``--dry-run-topology`` (with ``--gpus N``): no timed steps -- every rank reports its device UUID, the run fails if two ranks share a device
+although enough are visible (virnet_amd.dist.rank_topology), and the start-up weight broadcast is timed on its own.  ``--guard sync|deferred``:
+how the timed inference forwards learn of an fp16-range overflow (engine.guard_check_mode; default deferred = no host wait per forward, every
+forward checked before the clock stops).  Defaults: 30 timed steps behind 10 warm-up steps (the socket needs ~0.2 s of load to settle at its cap).
+
+Rank 0 prints ONE JSON line whose FIRST key, ``summary``, holds the seven headline values; besides the contract fields it carries
   roofline     : the dominant kernel = the launch group of the C->C 3x3 res-block convs with the most time (conv_f16_kernel by
                  default; conv_wino_row_kernel / conv_mfma_kernel with VIRNET_CONV_FORM=wino|direct).  Launch durations are
                  measured with HIP events recorded on the launch stream around every launch inside the timed region (rank 0).
@@ -291,12 +296,10 @@ def main():
         mine = (str(getattr(props, "uuid", "")) or f"index{dev.index}", torch.cuda.device_count())
         seen = [None] * world
         torch.distributed.all_gather_object(seen, mine)
-        distinct = len({u for u, _ in seen})
-        enough = min(c for _, c in seen) >= world
-        topo = {"ranks": world, "ranks_seen": distinct, "devices_visible_per_rank": [c for _, c in seen], "uuids": [u for u, _ in seen]}
-        if distinct < world and enough:
-            raise SystemExit(f"bench.py: {world} ranks landed on {distinct} distinct devices although every rank sees >= {world} devices "
-                             f"({topo['uuids']}): refusing to report a multi-GPU number (check LOCAL_RANK / HIP_VISIBLE_DEVICES)")
+        try:
+            topo = vdist.rank_topology(seen, world)
+        except RuntimeError as exc:
+            raise SystemExit(f"bench.py: {exc}")
     if args.dry_run_topology:
         reps = []
         for _ in range(3):

@@ -146,3 +146,19 @@ def test_reducer_gradients_do_not_alias_buckets():
         assert all(out[p].data_ptr() not in bucket_ptrs for p in ps)
     assert torch.equal(ps[0].grad, torch.full((5,), 1.0 + 2.0 + 3.0))          # accumulation over three steps, not 2x the last
     assert torch.equal(ps[1].grad, torch.full((3, 2), 10.0 + 11.0 + 12.0))
+
+
+def test_rank_topology_refuses_shared_devices_when_enough_are_visible():
+    """bench.py's multi-GPU guard: ranks piled on one device are an error when every rank sees enough devices, the
+    declared 1-GPU rehearsal (fewer devices than ranks) passes, and the block reports what the driver needs to see."""
+    from virnet_amd.dist import rank_topology
+    ok = rank_topology([(f"GPU-{i}", 8) for i in range(8)], 8)
+    assert ok["ranks_seen"] == 8 and ok["ranks"] == 8 and ok["devices_visible_per_rank"] == [8] * 8
+    rehearsal = rank_topology([("GPU-0", 1)] * 8, 8)                   # one visible device per rank: rehearsal on a 1-GPU box
+    assert rehearsal["ranks_seen"] == 1
+    with pytest.raises(RuntimeError, match="refusing to report"):
+        rank_topology([("GPU-0", 8), ("GPU-0", 8)] + [(f"GPU-{i}", 8) for i in range(2, 8)], 8)      # two ranks on GPU-0, 8 visible
+    with pytest.raises(RuntimeError, match="distinct devices"):
+        rank_topology([("GPU-3", 4)] * 4, 4)
+    with pytest.raises(ValueError):
+        rank_topology([("GPU-0", 1)], 2)

@@ -222,3 +222,23 @@ def test_bench_eight_rank_rehearsal_is_not_host_bound():
         # enqueueing one step on an empty queue, 8 processes at it together: << the 22 ms the 32-image step keeps a GPU busy
         # (enqueue_ms_per_step is NOT that: with the 8 ranks time-sharing this box's one GPU the launch queue fills and the call blocks)
         assert r["host_ms_one_step_empty_queue"] <= 8.0, r
+
+
+def test_bench_dry_run_topology_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2 --dry-run-topology`: no timed steps; every rank's device is reported, the 42-MB weight broadcast
+    is timed on its own, and the 1-GPU rehearsal (fewer devices than ranks) is let through -- virnet_amd.dist.rank_topology refuses the
+    same picture when enough devices are visible (tests/test_dist_cpu.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VIRNET_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-topology"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])["dry_run_topology"]
+    assert d["ranks"] == 2 and d["ranks_seen"] == 1 and len(d["uuids"]) == 2 and d["backend"] == "gloo"
+    assert d["broadcast_bytes"] == 42157328 and len(d["broadcast_ms"]) == 3 and min(d["broadcast_ms"]) > 0

@@ -61,6 +61,21 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> i
     return flat.numel() * 4
 
 
+def rank_topology(seen, world: int) -> dict:
+    """``seen`` = one ``(device uuid, devices visible to that rank)`` pair per rank.  Returns the topology block of the benchmark line and
+    raises when two ranks share a device ALTHOUGH every rank sees at least ``world`` devices -- a launcher that hides devices per rank or a
+    wrong LOCAL_RANK must not produce a "scaling" number (fewer devices than ranks is the declared rehearsal mode of a 1-GPU box).
+    Reference launch pattern: train_denoising_syn.py:280-297 (one process per visible GPU)."""
+    uuids, counts = [u for u, _ in seen], [int(c) for _, c in seen]
+    if len(seen) != world:
+        raise ValueError(f"rank_topology: {len(seen)} reports for {world} ranks")
+    topo = {"ranks": world, "ranks_seen": len(set(uuids)), "devices_visible_per_rank": counts, "uuids": uuids}
+    if topo["ranks_seen"] < world and min(counts) >= world:
+        raise RuntimeError(f"{world} ranks landed on {topo['ranks_seen']} distinct devices although every rank sees >= {world} devices ({uuids}): "
+                           "refusing to report a multi-GPU number (check LOCAL_RANK / HIP_VISIBLE_DEVICES)")
+    return topo
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     """MAX all-reduce of a python float (the benchmark's wall time)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
