@@ -312,3 +312,31 @@ def test_wx4_abi_rejects_bad_descriptors():
         assert lib.virnet_conv_wx4(C.byref(desc(**bad)), nat.stream_handle()) != 0, bad
         assert lib.virnet_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows", ["16", "8"])
+def test_store_policy_does_not_change_a_bit(rows, monkeypatch):
+    """VIRNET_NT_STORE_MB (round 5: non-temporal stores / residual loads for tensors larger than the Infinity Cache) is a cache-policy bit on
+    the same instructions: the Winograd convolution, the stride-2 and the transposed conv and the entry kernel give identical bits with it
+    forced on (1 MB) and off (0)."""
+    monkeypatch.setenv("VIRNET_CONV_FORM", "wx4")
+    monkeypatch.setenv("VIRNET_WX4_ROWS", rows)
+    from virnet_amd.networks.params import ConvParam
+    torch.manual_seed(5)
+    x = (torch.rand(2, 40, 72, 96, device="cuda") - 0.5)
+    res = (torch.rand(2, 40, 72, 96, device="cuda") - 0.5)
+    c3 = ConvParam(96, 96, 3).cuda(); cs = ConvParam(96, 192, 3, stride=2).cuda(); ct = ConvParam(96, 64, 2, transposed=True, stride=2).cuda()
+    ce = ConvParam(3, 64, 3).cuda()
+    img = torch.rand(2, 3, 40, 72, device="cuda")
+    br = torch.rand(2, 80, 144, 64, device="cuda")
+    outs = {}
+    for mb in ("0", "1"):
+        monkeypatch.setenv("VIRNET_NT_STORE_MB", mb)
+        a = ops.conv_mfma(x, c3.packed(), res=res, want_raw=True)[0]
+        b = ops.conv_mfma(x, c3.packed(), in_slope=0.2, want_raw=False, want_act=True)[1]
+        c = ops.conv_mfma(x, cs.packed(), stride=2, want_raw=True)[0]
+        d = ops.conv_mfma(x, ct.packed(), res=br, want_raw=True)[0]
+        e = ops.conv_entry(img, ce.packed(), 40, 72, want_act=True, slope=0.25)
+        outs[mb] = [t.clone() for t in (a, b, c, d, e)]
+    for u, v in zip(outs["0"], outs["1"]):
+        assert torch.equal(u, v)

@@ -30,11 +30,8 @@ int* range_flag_ptr() {
 }
 
 int store_nt_for(size_t bytes) {
-  static long limit = -1;
-  if (limit < 0) {
-    const char* e = getenv("VIRNET_NT_STORE_MB");
-    limit = e ? atol(e) : 128;
-  }
+  const char* e = getenv("VIRNET_NT_STORE_MB");       // (read per launch: A/B runs and tests flip it inside one process)
+  const long limit = e ? atol(e) : 128;
   return limit > 0 && bytes > (size_t)limit * 1048576u;
 }
 

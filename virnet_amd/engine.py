@@ -201,7 +201,9 @@ def guard_check_mode() -> str:
       asynchronous copy of the flag into pinned memory + an event; the NEXT guarded forward of the thread (or ``guard_poll()``) looks at
       the copies that have landed, and for an overflowed forward warns and repeats THAT input with the fp32 kernels into the SAME
       output tensors -- stream-ordered behind whatever was enqueued meanwhile: loud (NaN) in between, correct afterwards.
-      At most MAX_PENDING forwards stay unchecked; ``guard_poll()`` settles all of them (call it before trusting outputs on the host)."""
+      At most MAX_PENDING forwards stay unchecked; ``guard_poll()`` settles all of them (call it before trusting outputs on the host).
+      The repair re-runs the forward on the INPUT TENSOR OBJECT it was given: a caller that overwrites its input buffer in place between
+      forwards must poll first (or use sync mode) -- the pending entry holds a reference, not a copy."""
     mode = ops._env("VIRNET_GUARD_CHECK", "sync")
     if mode not in ("sync", "deferred"):
         raise ValueError(f"VIRNET_GUARD_CHECK={mode!r}: expected sync or deferred")
