@@ -75,6 +75,22 @@ def test_y_channel_and_ssim():
     s_ab, s_ac = veval.calculate_ssim(a, b), veval.calculate_ssim(a, 255 - a)
     assert 0.5 < s_ab < 1.0 and s_ac < s_ab and veval.calculate_ssim(a, b) == veval.calculate_ssim(b, a)
     assert veval.calculate_ssim(a, b, border=3, ycbcr=True) <= 1.0
+    # an independent restatement of utils/util_image.py:17-37 on another library: cv2.getGaussianKernel(11, 1.5) is exp(-(i - 5)^2 / (2 * 1.5^2))
+    # normalised, cv2.filter2D is a correlation whose [5:-5, 5:-5] crop is scipy's 'valid' correlation
+    from scipy.signal import correlate2d
+    k = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2)); k /= k.sum()
+    win = np.outer(k, k)
+
+    def ssim_scipy(x, y):
+        x, y = x.astype(np.float64), y.astype(np.float64)
+        f = lambda t: correlate2d(t, win, mode="valid")        # noqa: E731
+        m1, m2 = f(x), f(y)
+        s1, s2, s12 = f(x * x) - m1 ** 2, f(y * y) - m2 ** 2, f(x * y) - m1 * m2
+        c1, c2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+        return float((((2 * m1 * m2 + c1) * (2 * s12 + c2)) / ((m1 ** 2 + m2 ** 2 + c1) * (s1 + s2 + c2))).mean())
+    want = float(np.mean([ssim_scipy(a[:, :, i], b[:, :, i]) for i in range(3)]))
+    assert veval.calculate_ssim(a, b) == pytest.approx(want, abs=1e-10)
+    assert veval.calculate_ssim(a, b, border=3, ycbcr=True) == pytest.approx(ssim_scipy(veval.rgb2y_uint8(a)[3:-3, 3:-3], veval.rgb2y_uint8(b)[3:-3, 3:-3]), abs=1e-10)
 
 
 @pytest.mark.gpu
