@@ -11,9 +11,13 @@
 // reading the input once: the kernel is HBM-bound (algorithmic bytes = N*H*W*Cin*4 in + 4 B per output value).
 //
 // Workgroup = 4 waves = one 8 x 32 output tile.  Its z is needed on the 10 x 34 halo = 340 pixels, walked as 11 blocks of 32 (flat
-// index, 12 surplus columns masked); block b belongs to wave b % 4.  Per block: Cin/16 chunks x (2 x 16-byte loads, exact hi/lo split,
-// 3 MFMAs); A fragments (2 KB per chunk) sit in LDS.  z goes to LDS as [row][pixel] fp32 with the row's inverse weight scale applied;
-// then thread = output pixel sums its 9 z values per channel, applies bias and the planar epilogue (VIRNET_NCHW_*) and stores 128-byte runs.
+// index, 12 surplus columns masked); block b belongs to wave b % 4.  Per block: Cin/16 chunks x (2 x 16-byte buffer loads -- a lane
+// outside the halo / the image reads zeros through an out-of-range offset -- exact hi/lo split, 3 MFMAs); two blocks per wave in flight;
+// A fragments (2 KB per chunk) sit in LDS.  z goes to LDS RAW as [row][pixel] fp32; then thread = output pixel sums its 9 z values per
+// channel times the row's inverse weight scale (a scalar), applies bias and the planar epilogue (VIRNET_NCHW_*) and stores 128-byte runs.
+// Nothing is read from global memory between the first pixel request and the last store except the pixels: scales, biases and the
+// residual's values are requested at the top (round 5, tools/exit_timeline.py: per-register scale loads inside the block loop and
+// per-channel scale / bias / residual loads behind the previous channel's store were 16 + 3 dependent round trips per tile, 0.28 -> 0.22 ms).
 #include "conv_f16_common.h"
 
 namespace {
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(256) void conv_exit_kernel(const FArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nch = NCH ? NCH : (a.Cin >> 4);
   char* const a_lds = smem;                                      // [chunk][hi|lo][64 lanes][16 B]
-  float* const z_lds = reinterpret_cast<float*>(smem + nch * 2048);   // [32 rows][EX_ZS]
+  float* const z_lds = reinterpret_cast<float*>(smem + nch * 2048);   // [cout * 9 rows + 1 dummy][EX_ZS]
 
   const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
   const int tile = xcd * a.tiles_per_xcd + q;
@@ -40,12 +44,46 @@ __global__ __launch_bounds__(256) void conv_exit_kernel(const FArgs a) {
   const int ty = fast_div(trem, a.mg_ntx), tx = trem - ty * a.ntx;
   const int oy0 = ty * EX_TH, ox0 = tx * EX_TW;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int nrows = a.cout * 9;
+  TSTAMP(0);
 
-  for (int i = tid * 16; i < nch * 2048; i += 256 * 16) *reinterpret_cast<f32x4*>(a_lds + i) = *reinterpret_cast<const f32x4*>(a.wimg + i);
+  if constexpr (NCH != 0) {                                       // (all pieces requested before the first lands: one round trip)
+    f32x4 wv[NCH / 2];
+#pragma unroll
+    for (int i = 0; i < NCH / 2; ++i) wv[i] = *reinterpret_cast<const f32x4*>(a.wimg + i * 4096 + tid * 16);
+#pragma unroll
+    for (int i = 0; i < NCH / 2; ++i) *reinterpret_cast<f32x4*>(a_lds + i * 4096 + tid * 16) = wv[i];
+  } else {
+    for (int i = tid * 16; i < nch * 2048; i += 256 * 16) *reinterpret_cast<f32x4*>(a_lds + i) = *reinterpret_cast<const f32x4*>(a.wimg + i);
+  }
   __syncthreads();
+  TSTAMP(1);
+
+  // thread = output pixel of the epilogue.  The residual's values (cout <= 3) are requested HERE, before the pixel blocks: they have landed
+  // long before the shift-add wants them (requested there, they were one more HBM round trip between the barrier and the stores).
+  const int oyl = tid >> 5, oxl = tid & 31;
+  const int oy = oy0 + oyl, ox = ox0 + oxl;
+  const bool inside = oy < a.crop_h && ox < a.crop_w;
+  const size_t plane = (size_t)a.crop_h * a.crop_w;
+  const size_t o0 = (size_t)img * a.cout * plane + (size_t)oy * a.crop_w + ox;
+  // ... and the rows' inverse scales and the biases are read NOW, as scalars: behind the first store the compiler can no longer prove them
+  // unchanged and reads them per channel with vector loads whose wait also waits for the previous channel's store (one more round trip each)
+  float scv[27], bsv[3];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) scv[i] = a.inv_scale[i];          // (the packed image always holds 32 scales)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) bsv[c] = (a.bias && c < a.cout) ? a.bias[c] : 0.f;
+  float rv[3] = {0.f, 0.f, 0.f};
+  if (a.nchw_op == VIRNET_NCHW_ADD && inside) {
+    const int rw = a.crop_w / a.res_sf;
+    const size_t rplane = (size_t)(a.crop_h / a.res_sf) * rw;
+    const size_t r0 = (size_t)img * a.cout * rplane + (size_t)(oy / a.res_sf) * rw + ox / a.res_sf;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < a.cout) rv[c] = a.res[a.res_sf > 1 ? r0 + c * rplane : o0 + c * plane];
+  }
 
   const float* const ximg = a.x + (size_t)img * a.H * a.W * a.Cin;
   float amax = 0.f;
@@ -69,40 +107,54 @@ __global__ __launch_bounds__(256) void conv_exit_kernel(const FArgs a) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
   };
   auto put_z = [&](int blk, const f32x16& acc) {
-    // z[row][p] = acc * inverse scale of the row; accumulator register r of lane (l31, lhi) is row 8*(r>>2) + 4*lhi + (r&3), column l31
+    // z[row][p] = the RAW accumulator (the row's inverse weight scale, a power of two, is applied by the shift-add: there it is a scalar
+    // operand).  Accumulator register r of lane (l31, lhi) is row 8*(r>>2) + 4*lhi + (r&3), column l31; rows beyond the cout * 9 real ones
+    // land in ONE dummy row behind them -- sixteen unconditional ds_write_b32.  (Round 5: the scale used to be read from global memory
+    // here, one load + s_waitcnt vmcnt(0) per register inside the block loop -- sixteen dependent round trips per block, each of which
+    // also drained the NEXT block's prefetched pixels: 42 of a workgroup's 55 k cycles, tools/exit_timeline.py.)
     const int p = blk * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 8 * (r >> 2) + 4 * lhi + (r & 3);
-      if (row < nrows) z_lds[row * EX_ZS + p] = acc[r] * a.inv_scale[row];
+      z_lds[min(row, nrows) * EX_ZS + p] = acc[r];
     }
   };
   if constexpr (NCH != 0) {
-    // the next block's pixels are requested before this block is multiplied: a wave keeps 2 x NCH x 32 B per lane in flight
-    f32x4 cur0[NCH], cur1[NCH], nxt0[NCH], nxt1[NCH];
-    auto request = [&](const float* px, f32x4 (&v0)[NCH], f32x4 (&v1)[NCH]) {
+    // A wave owns blocks wave, wave + 4, wave + 8 (the last one: waves 0..2).  TWO blocks' pixels are in flight per wave (2 x NCH x 32 B per
+    // lane, ping-pong register sets, no copies); buffer loads, so that a lane outside the halo / the image reads zeros through an
+    // out-of-range offset -- no branch around the loads, and no wait for a load in flight before a masked lane's zero is written.
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, a.H * a.W * a.Cin * 4, 0x00020000);
+    auto pixel_off = [&](int blk) -> unsigned {
+      const int p = blk * 32 + l31;
+      const int hy = p / EX_HW, hx = p - hy * EX_HW;
+      const int gy = oy0 - 1 + hy, gx = ox0 - 1 + hx;
+      const bool valid = p < EX_HPX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      return valid ? (unsigned)(((gy * a.W + gx) * a.Cin + lhi * 8) * 4) : 0x80000000u;
+    };
+    auto request = [&](unsigned off, f32x4 (&v0)[NCH], f32x4 (&v1)[NCH]) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        v0[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        v1[c] = v0[c];
-        if (px) {
-          v0[c] = *reinterpret_cast<const f32x4*>(px + c * 16);
-          v1[c] = *reinterpret_cast<const f32x4*>(px + c * 16 + 4);
-        }
+        v0[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off + c * 64, 0, 0));
+        v1[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off + c * 64 + 16, 0, 0));
       }
     };
-    request(pixel_of(wave), cur0, cur1);
-    for (int blk = wave; blk < EX_BLK; blk += 4) {
-      request(pixel_of(blk + 4), nxt0, nxt1);
+    auto compute = [&](int blk, f32x4 (&v0)[NCH], f32x4 (&v1)[NCH]) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) mma(acc, c, cur0[c], cur1[c]);
+      for (int c = 0; c < NCH; ++c) mma(acc, c, v0[c], v1[c]);
       put_z(blk, acc);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) { cur0[c] = nxt0[c]; cur1[c] = nxt1[c]; }
-    }
+    };
+    static_assert(EX_BLK > 8 && EX_BLK <= 12, "three blocks per wave at most, two at least");
+    f32x4 p0[NCH], p1[NCH], q0[NCH], q1[NCH];
+    const bool third = wave + 8 < EX_BLK;                 // (wave-uniform)
+    request(pixel_off(wave), p0, p1);
+    request(pixel_off(wave + 4), q0, q1);
+    compute(wave, p0, p1);
+    if (third) request(pixel_off(wave + 8), p0, p1);
+    compute(wave + 4, q0, q1);
+    if (third) compute(wave + 8, p0, p1);
   } else {
     for (int blk = wave; blk < EX_BLK; blk += 4) {
       const float* const px = pixel_of(blk);
@@ -121,34 +173,39 @@ __global__ __launch_bounds__(256) void conv_exit_kernel(const FArgs a) {
       put_z(blk, acc);
     }
   }
+  TSTAMP(2);
   range_report(a.range_flag, amax);
   __syncthreads();
+  TSTAMP(3);
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && tid == 0) {
+    a.tlog[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);     // HW_REG_HW_ID
+    a.tlog[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID
+  }
+#endif
 
   // ---- shift-add + planar epilogue: thread = output pixel
-  const int oyl = tid >> 5, oxl = tid & 31;
-  const int oy = oy0 + oyl, ox = ox0 + oxl;
-  if (oy >= a.crop_h || ox >= a.crop_w) return;
-  const size_t plane = (size_t)a.crop_h * a.crop_w;
-  for (int c = 0; c < a.cout; ++c) {
-    float v = a.bias ? a.bias[c] : 0.f;
-    const float* const zc = z_lds + (c * 9) * EX_ZS + oyl * EX_HW + oxl;
+  if (!inside) return;
+  float outv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = bsv[c];
+    const float* const zc = z_lds + (c < a.cout ? c * 9 : 0) * EX_ZS + oyl * EX_HW + oxl;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) v += zc[(dy * 3 + dx) * EX_ZS + dy * EX_HW + dx];
-    const size_t o = ((size_t)img * a.cout + c) * plane + (size_t)oy * a.crop_w + ox;
-    if (a.nchw_op == VIRNET_NCHW_ADD) {
-      if (a.res_sf > 1) {
-        const int rw = a.crop_w / a.res_sf;
-        v += a.res[((size_t)img * a.cout + c) * (size_t)(a.crop_h / a.res_sf) * rw + (size_t)(oy / a.res_sf) * rw + ox / a.res_sf];
-      } else {
-        v += a.res[o];
-      }
-    } else if (a.nchw_op == VIRNET_NCHW_EXPCLAMP) {
-      v = expf(fminf(fmaxf(v, a.clamp_lo), a.clamp_hi));
-    }
-    a.y_raw[o] = v;
+      for (int dx = 0; dx < 3; ++dx) v += zc[(dy * 3 + dx) * EX_ZS + dy * EX_HW + dx] * scv[c * 9 + dy * 3 + dx];
+    if (a.nchw_op == VIRNET_NCHW_ADD) v += rv[c];
+    else if (a.nchw_op == VIRNET_NCHW_EXPCLAMP) v = expf(fminf(fmaxf(v, a.clamp_lo), a.clamp_hi));
+    outv[c] = v;
   }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    if (c < a.cout) a.y_raw[o0 + c * plane] = outv[c];
+#ifdef VIRNET_F16_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TSTAMP(4);
 }
 
 // rows (c, tap = dy*3 + dx) of the pointwise GEMM: per-row power-of-two scale (largest scaled magnitude in [8192, 16384)), split image
@@ -188,7 +245,7 @@ __global__ void pack_exit_kernel(const float* __restrict__ w, int cout, int cin,
 template <int NCH>
 int launch_exit(FArgs k, hipStream_t st) {
   const int nch = k.Cin >> 4;
-  const int lds = nch * 2048 + k.cout * 9 * EX_ZS * 4;          // A fragments + the (channel, tap) rows of z
+  const int lds = nch * 2048 + (k.cout * 9 + 1) * EX_ZS * 4;    // A fragments + the (channel, tap) rows of z + the dummy row
   static unsigned long long attr_done = 0;
   auto kern = conv_exit_kernel<NCH>;
   if (virnet::first_use_on_device(attr_done)) {
@@ -199,7 +256,14 @@ int launch_exit(FArgs k, hipStream_t st) {
   return virnet::check_launch("conv_exit launch");
 }
 
+#ifdef VIRNET_F16_TIMING
+long long* g_xlog = nullptr;
+#endif
 }  // namespace
+
+#ifdef VIRNET_F16_TIMING
+extern "C" void virnet_debug_exit_timing_buffer(void* p) { g_xlog = static_cast<long long*>(p); }   // tools/exit_timeline.py
+#endif
 
 extern "C" size_t virnet_exit_weight_floats(int cin_pad) { return 32 + (size_t)cin_pad * 32; }      // 32 scales + cin_pad/16 x 2 KB
 
@@ -232,6 +296,9 @@ extern "C" int virnet_conv_exit(const virnet_conv_desc* d, void* stream) {
   k.in_act = d->in_act; k.in_slope = d->in_slope;
   k.nchw_op = d->nchw_op; k.crop_h = d->crop_h; k.crop_w = d->crop_w; k.res_sf = d->res_sf; k.clamp_lo = d->clamp_lo; k.clamp_hi = d->clamp_hi;
   k.range_flag = virnet::range_flag_ptr();
+#ifdef VIRNET_F16_TIMING
+  k.tlog = g_xlog;
+#endif
   // only the cropped region is produced
   k.nty = (d->crop_h + EX_TH - 1) / EX_TH;
   k.ntx = (d->crop_w + EX_TW - 1) / EX_TW;
@@ -244,6 +311,6 @@ extern "C" int virnet_conv_exit(const virnet_conv_desc* d, void* stream) {
   const int nch = d->cin_pad >> 4;
   if (nch == 6) return launch_exit<6>(k, st);
   if (nch == 4) return launch_exit<4>(k, st);
-  VIRNET_REQUIRE(nch * 2048 + 32 * EX_ZS * 4 <= 160 * 1024, "virnet_conv_exit: cin_pad=%d does not fit LDS", d->cin_pad);
+  VIRNET_REQUIRE(nch * 2048 + 33 * EX_ZS * 4 <= 160 * 1024, "virnet_conv_exit: cin_pad=%d does not fit LDS", d->cin_pad);
   return launch_exit<0>(k, st);
 }
