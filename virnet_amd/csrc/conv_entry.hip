@@ -148,6 +148,11 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
   request(tile);
   land();
   __syncthreads();
+  // Loads and stores share ONE in-order vmcnt on gfx950: a tile's pixels requested BEHIND the previous tile's stores cannot be waited for
+  // without waiting for those stores' acknowledgements as well (an HBM write round trip under load).  So the request for tile i + 2 goes out
+  // in FRONT of tile i's stores: when tile i + 1 has been multiplied, the wait for them leaves tile i's 24 stores per wave outstanding.
+  int nxt = tile + wgs_per_xcd;
+  if (nxt < t_hi) request(nxt);
 
   char* const tw = t_lds + wave * TBYTES;
   const float slope = a.y_act ? a.slope : 1.f;
@@ -155,9 +160,7 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
   constexpr int UPP = NSLAB * 8;                                   // 16-byte units per pixel
   constexpr int NU = EN_TW * UPP / 64;                             // store instructions per row
   for (;;) {
-    const int nxt = tile + wgs_per_xcd;
-    const bool more = nxt < t_hi;
-    if (more) request(nxt);                                        // in flight behind this tile's MFMAs
+    const bool more = nxt < t_hi;                                  // (its pixels are in flight)
 
     const int img = fast_div(tile, a.mg_tpi);
     const int trem = tile - img * (a.ntx * a.nty);
@@ -215,9 +218,11 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
       for (int dy = 0; dy < 3; ++dy) kernel_row(dy);
     }
 
+    const int nxt2 = nxt + wgs_per_xcd;
     if (more) {                                                    // the next tile's pixels are on the chip before this tile's stores leave
       __syncthreads();                                             // (every wave has gathered its last fragment of this tile)
       land();
+      if (nxt2 < t_hi) request(nxt2);
     }
 
     // ---- epilogue: inverse scale, bias, optional LeakyReLU; per row a wave-private LDS turn-around, then lane-linear 1-KB stores.
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
     if (act) epilogue(std::true_type{}); else epilogue(std::false_type{});      // (uniform: the head stores raw values)
     if (!more) break;
     tile = nxt;
+    nxt = nxt2;
     __syncthreads();          // every wave has landed its share of the next tile
   }
   range_report(a.range_flag, amax);
