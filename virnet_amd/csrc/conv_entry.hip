@@ -154,6 +154,14 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
   int nxt = tile + wgs_per_xcd;
   if (nxt < t_hi) request(nxt);
 
+#ifdef VIRNET_F16_TIMING
+  long long tq_mma = 0, tq_land = 0, tq_epi = 0, tq_bar = 0, tq_mark = (long long)__builtin_amdgcn_s_memtime();
+  const long long tq_start = tq_mark;
+  int tq_tiles = 0;
+#define EN_TADD(var) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); var += n_ - tq_mark; tq_mark = n_; } while (0)
+#else
+#define EN_TADD(var) do { } while (0)
+#endif
   char* const tw = t_lds + wave * TBYTES;
   const float slope = a.y_act ? a.slope : 1.f;
   const bool act = a.y_act != nullptr && a.slope != 1.f;
@@ -218,12 +226,14 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
       for (int dy = 0; dy < 3; ++dy) kernel_row(dy);
     }
 
+    EN_TADD(tq_mma);
     const int nxt2 = nxt + wgs_per_xcd;
     if (more) {                                                    // the next tile's pixels are on the chip before this tile's stores leave
       __syncthreads();                                             // (every wave has gathered its last fragment of this tile)
       land();
       if (nxt2 < t_hi) request(nxt2);
     }
+    EN_TADD(tq_land);
 
     // ---- epilogue: inverse scale, bias, optional LeakyReLU; per row a wave-private LDS turn-around, then lane-linear 1-KB stores.
     // Accumulator register r of lane (l31, lhi) = channel 8 (r >> 2) + 4 lhi + (r & 3) of pixel l31 (conv_f16.hip).
@@ -265,11 +275,22 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
     }
     };
     if (act) epilogue(std::true_type{}); else epilogue(std::false_type{});      // (uniform: the head stores raw values)
+    EN_TADD(tq_epi);
+#ifdef VIRNET_F16_TIMING
+    ++tq_tiles;
+#endif
     if (!more) break;
     tile = nxt;
     nxt = nxt2;
     __syncthreads();          // every wave has landed its share of the next tile
+    EN_TADD(tq_bar);
   }
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && tid == 0) {
+    long long* const o = a.tlog + (size_t)blockIdx.x * 8;
+    o[0] = tq_start; o[1] = tq_mma; o[2] = tq_land; o[3] = tq_epi; o[4] = tq_bar; o[5] = tq_tiles; o[6] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
   range_report(a.range_flag, amax);
 }
 
@@ -356,6 +377,11 @@ extern "C" int virnet_pack_entry_weight(const float* w, int cout, int cin, int n
   return virnet::check_launch("pack_entry launch");
 }
 
+#ifdef VIRNET_F16_TIMING
+static long long* g_elog = nullptr;
+extern "C" void virnet_debug_entry_timing_buffer(void* p) { g_elog = static_cast<long long*>(p); }   // tools/entry_timeline.py
+#endif
+
 extern "C" int virnet_conv_entry(const virnet_conv_desc* d, const virnet_pack_desc* e, void* stream) {
   VIRNET_REQUIRE(d != nullptr && e != nullptr, "virnet_conv_entry: NULL descriptor");
   VIRNET_REQUIRE(e->x && d->wpack, "virnet_conv_entry: image / wpack is NULL");
@@ -379,6 +405,9 @@ extern "C" int virnet_conv_entry(const virnet_conv_desc* d, const virnet_pack_de
   k.N = d->n; k.H = d->h; k.W = d->w; k.Cin = nchan; k.cout = d->cout; k.NP = d->n_pad; k.slope = d->slope;
   k.ent = *e;
   k.range_flag = virnet::range_flag_ptr();
+#ifdef VIRNET_F16_TIMING
+  k.tlog = g_elog;
+#endif
   k.store_nt = virnet::store_nt_for((size_t)d->n * d->h * d->w * d->cout * 4);
   k.nty = (d->h + EN_TH - 1) / EN_TH;
   k.ntx = (d->w + EN_TW - 1) / EN_TW;
