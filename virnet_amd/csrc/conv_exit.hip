@@ -288,7 +288,7 @@ extern "C" int virnet_conv_exit(const virnet_conv_desc* d, void* stream) {
   VIRNET_REQUIRE(d->nchw_op != VIRNET_NCHW_ADD || d->res, "virnet_conv_exit: VIRNET_NCHW_ADD without res");
   VIRNET_REQUIRE(d->res_sf >= 1 && d->crop_h % d->res_sf == 0 && d->crop_w % d->res_sf == 0, "virnet_conv_exit: res_sf=%d does not divide the crop", d->res_sf);
   VIRNET_REQUIRE(!d->mask && !d->mul && !d->in_mul && !d->y_act, "virnet_conv_exit: plain planar epilogue only");
-  VIRNET_REQUIRE((long)d->h * d->w * d->cin_pad * 4 < (1L << 40), "virnet_conv_exit: input too large");
+  VIRNET_REQUIRE((long)d->h * d->w * d->cin_pad * 4 < (1L << 31), "virnet_conv_exit: one image's input (%d x %d x %d fp32) must stay below 2 GB (32-bit buffer offsets)", d->h, d->w, d->cin_pad);
   FArgs k{};
   k.x = d->x; k.inv_scale = d->wpack; k.wimg = reinterpret_cast<const char*>(d->wpack + 32);
   k.bias = d->bias; k.res = d->res; k.y_raw = d->y_raw;
