@@ -29,7 +29,7 @@ extern "C" {
 /* 2 (round 5): round 4's additions -- virnet_t_emit / virnet_knet_layer, the emitting and persistent entry points, the convT weight image
  * that keeps cin when cin % 32 == 0 -- were shipped under version 1; a stale library now fails the version check instead of an
  * AttributeError / a mis-sized packing. */
-#define VIRNET_ABI_VERSION 2
+#define VIRNET_ABI_VERSION 3
 
 int virnet_abi_version(void);
 const char* virnet_last_error(void);
@@ -396,6 +396,9 @@ typedef struct virnet_sft_weights {
 
 /* Spatially constant conditioning: mul[n][nf], add[n][nf] from vec[n][e] (AttLayer.forward, AttResUNet.py:27-32). */
 int virnet_sft_vec(const float* vec, const virnet_sft_weights* wt, float* mul, float* add, int n, void* stream);
+/* The same for `nlayers` (1..16) AttLayers on ONE vector in one launch (every AttResBlock.sft1 / sft2 of the down path, AttResUNet.py:50,57,
+ * depends on nothing but the conditioning vector): wts[l] -> muls[l][n][nf_l], adds[l][n][nf_l]; all layers take the same `e`.  (ABI 3) */
+int virnet_sft_vec_multi(const float* vec, const virnet_sft_weights* wts, int nlayers, float* const* muls, float* const* adds, int n, void* stream);
 
 /* Per-pixel conditioning: act = lrelu0.2(raw * mul(e) + add(e)) (AttResUNet.py:54-58) where e = channels
  * [chan0, chan0+wt->e) of the full-resolution 16-channel records rec[n][hp][wp][16] sampled at (y*step, x*step)

@@ -297,6 +297,20 @@ def test_sft_generators(nf, e):
     assert maxerr(nchw(got), ref) <= 2e-6
 
 
+def test_sft_vec_multi_is_bitwise_the_per_layer_launches():
+    """virnet_sft_vec_multi (every SFT layer of a down path in one launch, 16 layers per launch) against one virnet_sft_vec per layer."""
+    torch.manual_seed(34)
+    atts = [AttLayer(nf, 4).cuda() for nf in (96, 96, 160, 160, 224, 224) * 3]      # 18 layers: two launches
+    vec = rnd(3, 4, seed=35, lo=0, hi=1.5).cuda()
+    got = ops.sft_vec_multi(vec, atts)
+    assert len(got) == len(atts)
+    for att, (mul, add) in zip(atts, got):
+        m1, a1 = ops.sft_vec(vec, att)
+        assert torch.equal(mul, m1) and torch.equal(add, a1)
+    with pytest.raises(ValueError, match="conditioning vector"):
+        ops.sft_vec_multi(rnd(3, 5, seed=36).cuda(), atts[:2])
+
+
 def test_abi_rejects_bad_shapes():
     cp = make_conv(96, 96).cuda()
     with pytest.raises(ValueError, match="channels"):

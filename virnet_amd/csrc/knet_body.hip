@@ -29,9 +29,15 @@ constexpr int KB_PLANE = 4 * KB_CHUNK;           // 41472
 constexpr int KB_XBYTES = 2 * KB_PLANE;          // 82944
 constexpr int KB_WSTAGE = 12 * 1024;             // [slab 2][dy 3][hi|lo] x 1 KB
 constexpr int KB_SLAB_BYTES = 4 * 9 * 2048;      // one 32-row slab of the packed image: [chunk 4][tap 9][hi|lo][1 KB]
-constexpr int KB_RING = 6;                       // weight stages in LDS: five in flight ahead of the one being multiplied
+constexpr int KB_RING = 5;                       // weight stages in LDS: four in flight ahead of the one being multiplied
 constexpr int KB_RED = (8 * 64 + 64 + 16 + 64) * 4;
-constexpr int KB_LDS = KB_XBYTES + KB_RING * KB_WSTAGE + KB_RED;
+// the layer's small parameters, staged once per layer (round 5: read from global memory where they are used, they were ~10 dependent
+// round trips per layer behind s_waitcnt vmcnt(0) -- scale / bias vectors after each conv, the CALayer's two matrices in 16-float batches):
+// [inv1 64 | b1 64 | inv2 64 | b2 64 | cab1 16 | cab2 64 | caw1 cr x 64 (<= 1024) | caw2 64 x cr (<= 1024)]
+constexpr int KB_PAR_INV1 = 0, KB_PAR_B1 = 64, KB_PAR_INV2 = 128, KB_PAR_B2 = 192, KB_PAR_CAB1 = 256, KB_PAR_CAB2 = 272, KB_PAR_CAW1 = 336,
+              KB_PAR_CAW2 = 336 + 1024, KB_PAR_FLOATS = 336 + 2048;
+constexpr int KB_PAR_PT = (KB_PAR_FLOATS + 511) / 512;      // floats per thread
+constexpr int KB_LDS = KB_XBYTES + KB_RING * KB_WSTAGE + KB_RED + KB_PAR_FLOATS * 4;
 static_assert(KB_LDS <= 160 * 1024, "one workgroup per CU");
 constexpr int KB_MAX_LAYERS = 8;
 
@@ -53,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   float* const mean = part + 8 * 64;
   float* const f1 = mean + 64;
   float* const gate = f1 + 16;
+  float* const par = gate + 64;                                      // KB_PAR_FLOATS
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,14 +171,14 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
     gs0 += 12;
   };
   // acc * inverse row scale + bias, per channel of the accumulator layout
-  auto scale_bias = [&](f32x16 (&acc)[2], const float* pack, const float* bias) {
+  auto scale_bias = [&](f32x16 (&acc)[2], const float* inv, const float* bias) {      // (both in the LDS parameter block)
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = 32 * mb + 8 * g + 4 * lhi;
-        const f32x4 iv = *reinterpret_cast<const f32x4*>(pack + c);
-        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(inv + c);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
         acc[mb][4 * g] = fmaf(acc[mb][4 * g], iv.x, bv.x);
         acc[mb][4 * g + 1] = fmaf(acc[mb][4 * g + 1], iv.y, bv.y);
         acc[mb][4 * g + 2] = fmaf(acc[mb][4 * g + 2], iv.z, bv.z);
@@ -182,17 +189,38 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   const float inv_hw = 1.f / (float)(a.h * a.w);
   for (int li = 0; li < a.nlayers; ++li) {
     const virnet_knet_layer& L = a.L[li];
+    // this layer's small parameters: requested now (the loads are older than every weight piece issued from here on, so the waits inside
+    // conv() retire them), written to LDS behind conv1's last barrier -- where the previous layer's CALayer has long finished reading
+    float pv[KB_PAR_PT];
+#pragma unroll
+    for (int i = 0; i < KB_PAR_PT; ++i) {
+      const int j = i * 512 + tid;
+      const float* src = nullptr;
+      if (j < KB_PAR_B1) src = L.w1pack + j;
+      else if (j < KB_PAR_INV2) src = L.b1 ? L.b1 + (j - KB_PAR_B1) : nullptr;
+      else if (j < KB_PAR_B2) src = L.w2pack + (j - KB_PAR_INV2);
+      else if (j < KB_PAR_CAB1) src = L.b2 ? L.b2 + (j - KB_PAR_B2) : nullptr;
+      else if (j < KB_PAR_CAB2) src = j - KB_PAR_CAB1 < a.cr ? L.cab1 + (j - KB_PAR_CAB1) : nullptr;
+      else if (j < KB_PAR_CAW1) src = L.cab2 + (j - KB_PAR_CAB2);
+      else if (j < KB_PAR_CAW2) src = j - KB_PAR_CAW1 < a.cr * 64 ? L.caw1 + (j - KB_PAR_CAW1) : nullptr;
+      else if (j < KB_PAR_FLOATS) src = j - KB_PAR_CAW2 < 64 * a.cr ? L.caw2 + (j - KB_PAR_CAW2) : nullptr;
+      pv[i] = src ? *src : 0.f;
+    }
     put_split(cur);
     f32x16 t[2];
     conv(t);                                                          // KNet.py:32
-    scale_bias(t, L.w1pack, L.b1);
+#pragma unroll
+    for (int i = 0; i < KB_PAR_PT; ++i)
+      if (i * 512 + tid < KB_PAR_FLOATS) par[i * 512 + tid] = pv[i];
+    __syncthreads();
+    scale_bias(t, par + KB_PAR_INV1, par + KB_PAR_B1);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[mb][r] = inside ? kb_lrelu(t[mb][r], 0.2f) : 0.f;   // KNet.py:33; outside the map: padding
     put_split(t);
     conv(t);                                                          // KNet.py:34
-    scale_bias(t, L.w2pack, L.b2);
+    scale_bias(t, par + KB_PAR_INV2, par + KB_PAR_B2);
     // ---- CALayer (KNet.py:15-26): channel means -> gate
     float ps[2][16];
 #pragma unroll
@@ -221,14 +249,14 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
     }
     __syncthreads();
     if (tid < a.cr) {
-      float s = L.cab1[tid];
-      for (int k = 0; k < 64; ++k) s = fmaf(L.caw1[tid * 64 + k], mean[k], s);
+      float s = par[KB_PAR_CAB1 + tid];
+      for (int k = 0; k < 64; ++k) s = fmaf(par[KB_PAR_CAW1 + tid * 64 + k], mean[k], s);
       f1[tid] = kb_lrelu(s, 0.2f);
     }
     __syncthreads();
     if (tid < 64) {
-      float s = L.cab2[tid];
-      for (int k = 0; k < a.cr; ++k) s = fmaf(L.caw2[tid * a.cr + k], f1[k], s);
+      float s = par[KB_PAR_CAB2 + tid];
+      for (int k = 0; k < a.cr; ++k) s = fmaf(par[KB_PAR_CAW2 + tid * a.cr + k], f1[k], s);
       gate[tid] = 1.f / (1.f + expf(-s));
     }
     __syncthreads();

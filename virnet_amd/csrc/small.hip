@@ -274,11 +274,8 @@ __global__ __launch_bounds__(256) void sft_backward_kernel(const float4* __restr
 }
 
 // AttLayer on a per-image vector: block per image
-__global__ __launch_bounds__(256) void sft_vec_kernel(const float* __restrict__ vec, const virnet_sft_weights wt,
-                                                      float* __restrict__ mul, float* __restrict__ add) {
-  __shared__ float e[16];
-  __shared__ float f1[64];
-  __shared__ float f2[128];
+__device__ __forceinline__ void sft_vec_body(const float* __restrict__ vec, const virnet_sft_weights& wt, float* __restrict__ mul,
+                                             float* __restrict__ add, float* e, float* f1, float* f2) {
   const int img = blockIdx.x;
   if (threadIdx.x < wt.e) e[threadIdx.x] = vec[(size_t)img * wt.e + threadIdx.x];
   __syncthreads();
@@ -303,6 +300,30 @@ __global__ __launch_bounds__(256) void sft_vec_kernel(const float* __restrict__ 
     mul[(size_t)img * wt.nf + c] = sigmoidf(tm);
     add[(size_t)img * wt.nf + c] = ta;
   }
+}
+
+__global__ __launch_bounds__(256) void sft_vec_kernel(const float* __restrict__ vec, const virnet_sft_weights wt,
+                                                      float* __restrict__ mul, float* __restrict__ add) {
+  __shared__ float e[16];
+  __shared__ float f1[64];
+  __shared__ float f2[128];
+  sft_vec_body(vec, wt, mul, add, e, f1, f2);
+}
+
+// ... of SEVERAL AttLayers on the same vector in one launch (grid.y = layer): every SFT layer of the down path depends on nothing but the
+// conditioning vector, and a single-image SISR forward spent twelve dependent ~5-us launches on them (tools/probes/sisr_n1_trace.sh)
+constexpr int SFT_MULTI_MAX = 16;
+struct SftMulti {
+  virnet_sft_weights wt[SFT_MULTI_MAX];
+  float* mul[SFT_MULTI_MAX];
+  float* add[SFT_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void sft_vec_multi_kernel(const float* __restrict__ vec, const SftMulti m) {
+  __shared__ float e[16];
+  __shared__ float f1[64];
+  __shared__ float f2[128];
+  const int l = blockIdx.y;
+  sft_vec_body(vec, m.wt[l], m.mul[l], m.add[l], e, f1, f2);
 }
 
 // AttLayer per pixel + SFT + LeakyReLU: block = PT pixels; thread <-> output channel (looped), weights read once per block
@@ -478,6 +499,21 @@ extern "C" int virnet_sft_vec(const float* vec, const virnet_sft_weights* wt, fl
   if (int rc = check_sft(wt, "virnet_sft_vec")) return rc;
   hipLaunchKernelGGL(sft_vec_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), vec, *wt, mul, add);
   return virnet::check_launch("sft_vec launch");
+}
+
+extern "C" int virnet_sft_vec_multi(const float* vec, const virnet_sft_weights* wts, int nlayers, float* const* muls, float* const* adds, int n,
+                                    void* stream) {
+  VIRNET_REQUIRE(vec && wts && muls && adds && n > 0, "virnet_sft_vec_multi: bad arguments");
+  VIRNET_REQUIRE(nlayers >= 1 && nlayers <= SFT_MULTI_MAX, "virnet_sft_vec_multi: %d layers (1..%d per call)", nlayers, SFT_MULTI_MAX);
+  SftMulti m{};
+  for (int l = 0; l < nlayers; ++l) {
+    if (int rc = check_sft(wts + l, "virnet_sft_vec_multi")) return rc;
+    VIRNET_REQUIRE(wts[l].e == wts[0].e, "virnet_sft_vec_multi: layer %d takes %d conditioning channels, layer 0 takes %d", l, wts[l].e, wts[0].e);
+    VIRNET_REQUIRE(muls[l] && adds[l], "virnet_sft_vec_multi: layer %d has a NULL output", l);
+    m.wt[l] = wts[l]; m.mul[l] = muls[l]; m.add[l] = adds[l];
+  }
+  hipLaunchKernelGGL(sft_vec_multi_kernel, dim3(n, nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), vec, m);
+  return virnet::check_launch("sft_vec_multi launch");
 }
 
 extern "C" int virnet_sft_apply(const float* raw, const float* rec, const virnet_sft_weights* wt, float* act, int n, int h,

@@ -103,6 +103,11 @@ class _Cond:
 
     def __init__(self, vec: Optional[Tensor], rec: Optional[Tensor], chan0: int, nchan: int):
         self.vec, self.rec, self.chan0, self.nchan = vec, rec, chan0, nchan
+        self.pre = {}            # id(AttLayer) -> (mul, add) computed ahead for the whole down path (ops.sft_vec_multi)
+
+    def sft(self, att):
+        got = self.pre.get(id(att))
+        return got if got is not None else ops.sft_vec(self.vec, att)
 
 
 def _res_block(x_raw: Tensor, blk, cond: Optional[_Cond], level: int) -> Tensor:
@@ -112,8 +117,8 @@ def _res_block(x_raw: Tensor, blk, cond: Optional[_Cond], level: int) -> Tensor:
     if not sft:
         _, f1a = ops.conv_mfma(x_raw, c1, in_slope=0.2, want_raw=False, want_act=True, slope=0.2)
     elif cond.vec is not None:   # spatially constant conditioning: SFT collapses to per-(image, channel) scale/shift
-        mul1, add1 = ops.sft_vec(cond.vec, blk.sft1)
-        mul2, add2 = ops.sft_vec(cond.vec, blk.sft2)
+        mul1, add1 = cond.sft(blk.sft1)
+        mul2, add2 = cond.sft(blk.sft2)
         _, f1a = ops.conv_mfma(x_raw, c1, in_slope=0.2, in_mul=mul1, in_add=add1, mul=mul2, add=add2, want_raw=False,
                                want_act=True, slope=0.2)
     else:                        # per-pixel conditioning: materialise the two modulated tensors (rare configuration)
@@ -161,6 +166,11 @@ def rnet_forward(rnet, x_in: Tensor, *, extra_map: Optional[Tensor] = None, extr
     else:                                                                              # ... with the entry packing folded into the conv
         x = ops.conv_entry(x_in, rnet.head.packed(), Hp, Wp, sf=sf, vec=extra_vec if feed_head else None,
                            map_=extra_map if feed_head else None, map_sf=map_sf, map_sqrt=map_sqrt)
+    if cond is not None and cond.vec is not None and ops._env("VIRNET_SFT_MULTI", "1") != "0":
+        # every SFT layer of the down path sees the same vector: all their (mul, add) pairs in one launch, ahead of the first block
+        atts = [a for lvl in rnet.down_path for blk in lvl.body if blk.extra_chn > 0 for a in (blk.sft1, blk.sft2)]
+        if atts:
+            cond.pre = {id(a): ma for a, ma in zip(atts, ops.sft_vec_multi(cond.vec, atts))}
     bridges: List[Tensor] = []
     for ii, lvl in enumerate(rnet.down_path):
         for blk in lvl.body:

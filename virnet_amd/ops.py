@@ -107,7 +107,7 @@ DEFAULT_CONV_FORM = "wx4"
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_BIAS_FUSED", "VIRNET_ENTRY_FUSED", "VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
-          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM")
+          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM", "VIRNET_SFT_MULTI")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
     inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The
@@ -930,6 +930,35 @@ def sft_vec(vec: Tensor, att) -> Tuple[Tensor, Tensor]:
     nat.check(nat.load().virnet_sft_vec(nat.ptr(vec), C.byref(wt), nat.ptr(mul), nat.ptr(add), n, nat.stream_handle()),
               "sft_vec")
     return mul, add
+
+
+SFT_MULTI_MAX = 16
+
+
+def sft_vec_multi(vec: Tensor, atts) -> list:
+    """``sft_vec`` for several AttLayers on the same vector in ONE launch per 16 layers (virnet_sft_vec_multi): [(mul, add), ...] in the
+    order of ``atts``.  The SFT layers of a down path all depend on the conditioning vector alone; one launch instead of one per layer."""
+    _dev_check(vec, "vec")
+    n = vec.shape[0]
+    out = []
+    lib = nat.load()
+    for i0 in range(0, len(atts), SFT_MULTI_MAX):
+        group = atts[i0:i0 + SFT_MULTI_MAX]
+        wts = (nat.SftWeights * len(group))()
+        muls, adds = (C.c_void_p * len(group))(), (C.c_void_p * len(group))()
+        keep = []
+        for l, att in enumerate(group):
+            wt, ts = _sft_weights(att)
+            if vec.shape[1] != wt.e:
+                raise ValueError(f"conditioning vector has {vec.shape[1]} channels, AttLayer expects {wt.e}")
+            keep.append(ts)
+            wts[l] = wt
+            mul = torch.empty((n, wt.nf), dtype=torch.float32, device=vec.device)
+            add = torch.empty_like(mul)
+            muls[l], adds[l] = nat.ptr(mul), nat.ptr(add)
+            out.append((mul, add))
+        nat.check(lib.virnet_sft_vec_multi(nat.ptr(vec), wts, len(group), muls, adds, n, nat.stream_handle()), "sft_vec_multi")
+    return out
 
 
 def sft_apply(raw: Tensor, rec: Tensor, chan0: int, nchan: int, step: int, att) -> Tensor:
