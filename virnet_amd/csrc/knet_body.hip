@@ -47,6 +47,7 @@ struct KnetArgs {
   virnet_knet_layer L[KB_MAX_LAYERS];
   int nlayers, h, w, cr;
   int* range_flag;
+  long long* tlog;                               // -DVIRNET_F16_TIMING builds (tools/knet_timeline.py)
 };
 
 __device__ __forceinline__ float kb_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
@@ -104,6 +105,13 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
       }
   };
 
+#ifdef VIRNET_F16_TIMING
+  long long kq_mma = 0, kq_wait = 0, kq_rest = 0, kq_mark = (long long)__builtin_amdgcn_s_memtime();
+  const long long kq_start = kq_mark;
+#define KB_TADD(var) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); var += n_ - kq_mark; kq_mark = n_; } while (0)
+#else
+#define KB_TADD(var) do { } while (0)
+#endif
   const int lane16 = lane * 16;
   // ---- weight stream.  The 2 * nlayers convolutions are ONE sequence of stages gs = conv * 12 + (chunk * 3 + kernel column), 12 KB each
   // ([slab 2][dy 3][hi|lo] x 1 KB), living in a ring of KB_RING buffers; stage gs + KB_RING - 1 is requested when stage gs starts, so the
@@ -140,9 +148,11 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
     // X complete (this wave's LDS stores) and stage gs0 landed (this wave's pieces; the barrier publishes the others')
+    KB_TADD(kq_rest);
     if (gs0 + KB_RING - 1 <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 2)) & 15) | 0x0070);
     else __builtin_amdgcn_s_waitcnt(0x0070);
     asm volatile("s_barrier" ::: "memory");
+    KB_TADD(kq_wait);
     for (int s = 0; s < 12; ++s) {
       const int gs = gs0 + s;
       const char* const wb = w_lds + (gs % KB_RING) * KB_WSTAGE + lane16;
@@ -164,9 +174,11 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
       }
       // stage gs + 1 landed (the 2 * (KB_RING - 2) pieces of the stages behind it may stay in flight; near the end of the stream
       // fewer were issued: wait for all), then the barrier: this buffer is free, the next one visible
+      KB_TADD(kq_mma);
       if (gs + KB_RING <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 2)) & 15) | 0x0070);
       else __builtin_amdgcn_s_waitcnt(0x0070);
       asm volatile("s_barrier" ::: "memory");
+      KB_TADD(kq_wait);
     }
     gs0 += 12;
   };
@@ -221,43 +233,56 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
     put_split(t);
     conv(t);                                                          // KNet.py:34
     scale_bias(t, par + KB_PAR_INV2, par + KB_PAR_B2);
-    // ---- CALayer (KNet.py:15-26): channel means -> gate
-    float ps[2][16];
+    // ---- CALayer (KNet.py:15-26): channel means -> gate.  The per-channel sums over the wave's 32 pixels are a butterfly reduce-scatter
+    // (lane bit 4, 3, .. 0 decides which half of its values a lane keeps and which it hands to its partner): 31 cross-lane moves per lane
+    // instead of 5 x 32, and lane l31 ends up with the sum of value q = l31 (q = 16 mb + r) -- one channel per lane, fixed order.
+    float rs[32];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = inside ? t[mb][r] : 0.f;
+        const float v = inside ? t[mb][r] : 0.f;
         t[mb][r] = v;
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);   // over the 32 pixels of the wave, fixed tree
-        ps[mb][r] = v;
+        rs[16 * mb + r] = v;
       }
-    if (l31 == 0) {
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+    for (int half = 16; half >= 1; half >>= 1) {
+      const bool up = (l31 & half) != 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(part + wave * 64 + 32 * mb + 8 * g + 4 * lhi) = f32x4{ps[mb][4 * g], ps[mb][4 * g + 1], ps[mb][4 * g + 2], ps[mb][4 * g + 3]};
+      for (int i = 0; i < half; ++i) {
+        const float lo_v = rs[i], hi_v = rs[i + half];
+        const float give = up ? lo_v : hi_v, keep = up ? hi_v : lo_v;
+        rs[i] = keep + __shfl_xor(give, half, 64);
+      }
+    }
+    {
+      const int r = l31 & 15;
+      part[wave * 64 + 32 * (l31 >> 4) + 8 * (r >> 2) + 4 * lhi + (r & 3)] = rs[0];
+    }
+    __syncthreads();
+    // 64 -> cr: wave w owns outputs w and w + 8; lane k forms caw1[j][k] * mean[k] (every wave sums the 8 partial sums of its lane's channel
+    // itself), the 64 products meet in a lane reduction
+    {
+      float mk = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) mk += part[wv * 64 + lane];
+      mk *= inv_hw;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = wave + 8 * jj;
+        if (j < a.cr) {                                                // (wave-uniform)
+          float pr = par[KB_PAR_CAW1 + j * 64 + lane] * mk;
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) pr += __shfl_xor(pr, m, 64);
+          if (lane == 0) f1[j] = kb_lrelu(pr + par[KB_PAR_CAB1 + j], 0.2f);
+        }
+      }
     }
     __syncthreads();
     if (tid < 64) {
-      float s = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < 8; ++wv) s += part[wv * 64 + tid];
-      mean[tid] = s * inv_hw;
-    }
-    __syncthreads();
-    if (tid < a.cr) {
-      float s = par[KB_PAR_CAB1 + tid];
-      for (int k = 0; k < 64; ++k) s = fmaf(par[KB_PAR_CAW1 + tid * 64 + k], mean[k], s);
-      f1[tid] = kb_lrelu(s, 0.2f);
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float s = par[KB_PAR_CAB2 + tid];
-      for (int k = 0; k < a.cr; ++k) s = fmaf(par[KB_PAR_CAW2 + tid * a.cr + k], f1[k], s);
-      gate[tid] = 1.f / (1.f + expf(-s));
+      float sg = par[KB_PAR_CAB2 + tid];
+      for (int k = 0; k < a.cr; ++k) sg = fmaf(par[KB_PAR_CAW2 + tid * a.cr + k], f1[k], sg);
+      gate[tid] = 1.f / (1.f + expf(-sg));
     }
     __syncthreads();
     // ---- x + CA(h)  (KNet.py:38), registers only
@@ -272,6 +297,13 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
         cur[mb][4 * g + 3] = fmaf(t[mb][4 * g + 3], gv.w, cur[mb][4 * g + 3]);
       }
   }
+  KB_TADD(kq_rest);
+#ifdef VIRNET_F16_TIMING
+  if (a.tlog && tid == 0) {
+    long long* const o = a.tlog + (size_t)blockIdx.x * 8;
+    o[0] = kq_start; o[1] = kq_mma; o[2] = kq_wait; o[3] = kq_rest; o[4] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
   range_report(a.range_flag, amax);
   if (inside) {
     float* const py = a.y + (((size_t)img * a.h + prow) * a.w + pcol) * 64;
@@ -283,7 +315,14 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   }
 }
 
+#ifdef VIRNET_F16_TIMING
+long long* g_kblog = nullptr;
+#endif
 }  // namespace
+
+#ifdef VIRNET_F16_TIMING
+extern "C" void virnet_debug_knet_timing_buffer(void* p) { g_kblog = static_cast<long long*>(p); }
+#endif
 
 extern "C" int virnet_knet_body(const float* x, float* y, const virnet_knet_layer* layers, int nlayers, int n, int h, int w, int c, int cr,
                                 void* stream) {
@@ -308,6 +347,9 @@ extern "C" int virnet_knet_body(const float* x, float* y, const virnet_knet_laye
     a.nlayers = nlayers - l0 < KB_MAX_LAYERS ? nlayers - l0 : KB_MAX_LAYERS;
     for (int i = 0; i < a.nlayers; ++i) a.L[i] = layers[l0 + i];
     a.range_flag = virnet::range_flag_ptr();
+#ifdef VIRNET_F16_TIMING
+    a.tlog = g_kblog;
+#endif
     hipLaunchKernelGGL(knet_body_kernel, dim3((unsigned)n), dim3(512), KB_LDS, st, a);
     if (int rc = virnet::check_launch("knet_body launch")) return rc;
     src = y;
