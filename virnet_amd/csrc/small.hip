@@ -12,38 +12,55 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 // ----------------------------------------------------------------------------------------------------------------
 // KernelNet.head (networks/KNet.py:45,53): Conv2d(cin -> 64-multiple, k=9, s=4, p=4, no bias), NCHW in, NHWC out.
 // Block: 256 threads = 4 output pixels x 64 output channels; the [K][64] weight tile sits transposed in LDS (row stride 65
-// floats -> conflict-free for both the transposing write and the channel-parallel read).
+// floats -> conflict-free for both the transposing write and the channel-parallel read), and the 4 pixels' K input samples next to it
+// (zero where the 9 x 9 window leaves the image), so that a tap is two LDS reads and an FMA.  Round 5 (tools/probes/sisr_n1_trace.sh:
+// 32 us for one 64 x 64 image): the weight tile used to be staged by a load -> wait -> store loop of K * 64 / 256 = 61 dependent round
+// trips, and every tap read its input sample from global memory behind a bounds branch -- 243 more; now eight rows' loads are in flight
+// at a time and the samples of a pixel group arrive in one.
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_head_s4_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            float* __restrict__ out, int n, int cin, int h, int wd, int cout,
                                                            int oh, int ow, int pix_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][65]
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][65] | [4][K]
   const int K = cin * 81;
+  float* const xs = wl + K * 65;
   const int ctile = blockIdx.y;  // 64 output channels
-  for (int i = threadIdx.x; i < K * 64; i += 256) {
-    const int co = i / K, k = i - co * K;
-    wl[k * 65 + co] = w[(size_t)(ctile * 64 + co) * K + k];
+  // weights: row co of the tile = K contiguous floats; thread t takes column k = t (+ 256 ..) of eight rows at a time
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float* const wp = w + (size_t)ctile * 64 * K + k;
+#pragma unroll 1
+    for (int c0 = 0; c0 < 64; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = wp[(size_t)(c0 + j) * K];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wl[k * 65 + c0 + j] = v[j];
+    }
   }
-  __syncthreads();
   const int co = threadIdx.x & 63, ps = threadIdx.x >> 6;
   const long npix = (long)n * oh * ow;
   const long p0 = (long)blockIdx.x * pix_per_block;
-  for (long p = p0 + ps; p < p0 + pix_per_block && p < npix; p += 4) {
+  for (long pg = p0; pg < p0 + pix_per_block && pg < npix; pg += 4) {
+    __syncthreads();                                        // (weights staged / the previous group's samples consumed)
+    const long p = pg + ps;
+    const bool live = p < npix && p < p0 + pix_per_block;
     const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), img = (int)(p / ((long)ow * oh));
-    float acc = 0.f;
-    for (int ci = 0; ci < cin; ++ci) {
-      const float* xp = x + ((size_t)img * cin + ci) * h * wd;
-      for (int ky = 0; ky < 9; ++ky) {
-        const int iy = oy * 4 - 4 + ky;
-        if ((unsigned)iy >= (unsigned)h) continue;
-#pragma unroll
-        for (int kx = 0; kx < 9; ++kx) {
-          const int ix = ox * 4 - 4 + kx;
-          if ((unsigned)ix < (unsigned)wd) acc = fmaf(xp[(size_t)iy * wd + ix], wl[((ci * 9 + ky) * 9 + kx) * 65 + co], acc);
-        }
-      }
+    // this wave's pixel: sample k = (ci, ky, kx), lane l takes k = l, l + 64, ..
+    for (int k = co; k < K; k += 64) {
+      const int ci = k / 81, r = k - ci * 81, ky = r / 9, kx = r - ky * 9;
+      const int iy = oy * 4 - 4 + ky, ix = ox * 4 - 4 + kx;
+      float v = 0.f;
+      if (live && (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wd) v = x[(((size_t)img * cin + ci) * h + iy) * wd + ix];
+      xs[ps * K + k] = v;
     }
-    out[(size_t)p * cout + ctile * 64 + co] = acc;
+    __syncthreads();
+    if (live) {
+      float acc = 0.f;
+      const float* const xp = xs + ps * K;
+#pragma unroll 9
+      for (int k = 0; k < K; ++k) acc = fmaf(xp[k], wl[k * 65 + co], acc);      // (a sample outside the image is a zero: fma(0, w, acc) = acc)
+      out[(size_t)p * cout + ctile * 64 + co] = acc;
+    }
   }
 }
 
@@ -400,7 +417,7 @@ extern "C" int virnet_conv_head_s4(const float* x, const float* w, float* out, i
   VIRNET_REQUIRE(n > 0 && h > 0 && w_ > 0 && cin > 0, "virnet_conv_head_s4: bad shape");
   VIRNET_REQUIRE(cout % 64 == 0 && cout > 0, "virnet_conv_head_s4: cout=%d must be a multiple of 64", cout);
   const int K = cin * 81;
-  const size_t lds = (size_t)K * 65 * sizeof(float);
+  const size_t lds = ((size_t)K * 65 + 4 * (size_t)K) * sizeof(float);
   VIRNET_REQUIRE(lds <= 160 * 1024, "virnet_conv_head_s4: cin=%d too large for the LDS weight tile", cin);
   static unsigned long long attr_done = 0;     // one bit per device
   if (virnet::first_use_on_device(attr_done)) {
