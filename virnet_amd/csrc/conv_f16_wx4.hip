@@ -967,7 +967,8 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
     if (rows_pin == 16) return false;
     const long w16 = (long)d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * groups;
     const long w8 = (long)d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32) * groups;
-    if (pre == 2 && nrep == 3) return false;                   // (the 8-row form's 80 KB have no room for the SFT table next to three slabs)
+    if (pre == 2 && nrep == 3) return w8 <= n_cu;              // (the 8-row form's 80 KB have no room for the SFT table next to three slabs: one
+                                                               //  workgroup per CU -- which is all a launch of at most n_cu workgroups asks for: SISR, one image)
     if (w16 >= 8L * n_cu) return nrep <= 2;                     // chip filled many times over
     const double t16 = (double)((w16 + n_cu - 1) / n_cu);
     const long full = w8 / (2L * n_cu), tail = w8 - full * 2L * n_cu;
