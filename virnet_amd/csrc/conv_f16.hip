@@ -768,7 +768,11 @@ static int conv_f16_impl(const virnet_conv_desc* d, void* stream, int bf, const 
   // the largest 3-slab grid that is split (0 = never).
   {
     const char* const env_s = getenv("VIRNET_F16_SPLIT_WGS");
-    const long split_below = env_s ? atol(env_s) : 128;
+    // A MIXED grouping (160 = 3 + 2 slabs) is two launches one after the other, each on half of the chip when it has ~128 workgroups:
+    // there the split pays up to twice the grid (SISR x4, one image, 160-channel level: 2 x 128 workgroups in 58 us -> 640 in ~30;
+    // the forward 1.21 -> 1.08 ms, profiles/r05_probes.md 11)
+    const bool mixed = (n3 > 0) + (n2 > 0) + (n1 > 0) >= 2;
+    const long split_below = env_s ? atol(env_s) : (mixed ? 256 : 128);
     const long tiles4 = (long)d->n * ((d->h + 3) / 4) * ((d->w + 31) / 32);
     if (nb > 1 && tiles4 * (n3 + n2 + n1) <= split_below && !te) { n3 = 0; n2 = 0; n1 = nb; }
   }
