@@ -304,6 +304,17 @@ int virnet::launch_f16_s2(FArgs k, int nb, hipStream_t st) {
   // 160 and 224 channels (SISR: 5 / 7 slabs) as ONE 4-wave launch with 5 / 7 slabs per workgroup (the pixel tile staged once) instead of
   // 3 + 2 / 3 + 2 + 2: the workgroup is alone on its CU either way (75 KB pixel tiles), so its 512 registers per wave are there
   static const bool wide_off = getenv("VIRNET_S2_WIDE") && getenv("VIRNET_S2_WIDE")[0] == '0';      // (A/B knob)
+  // ... unless the launch is a few dozen tiles (SISR, one image: 160 -> 224 channels onto 64 x 64 = 32 tiles = 32 workgroups on 256 CUs,
+  // 54 us): then one slab per workgroup, all slabs in ONE launch (32 x 7 = 224 workgroups).  VIRNET_S2_SPLIT_TILES: the largest such launch.
+  const char* const env_t = getenv("VIRNET_S2_SPLIT_TILES");
+  const long split_tiles = env_t ? atol(env_t) : 64;
+  const long tiles_all = (long)k.N * ((k.OH + 3) / 4) * ((k.OW + 31) / 32);
+  if (nb > 1 && tiles_all <= split_tiles) {
+    FArgs kk = k;
+    kk.slab_base = 0;
+    kk.NP = nb * 32;
+    return launch<1, 1>(kk, st);
+  }
   if ((nb == 5 || nb == 7 || nb == 4) && !wide_off) {
     FArgs kk = k;
     kk.slab_base = 0;
