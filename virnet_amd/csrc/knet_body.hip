@@ -117,8 +117,8 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   // ([slab 2][dy 3][hi|lo] x 1 KB), living in a ring of KB_RING buffers; stage gs + KB_RING - 1 is requested when stage gs starts, so the
   // L2 latency of a piece (~1-2 us, several times the 0.25 us a stage multiplies) is covered five stages deep and the first stages of the
   // NEXT conv arrive while this conv's epilogue / CALayer runs.  Every wave issues exactly two pieces per stage (q = wave, wave + 8; the
-  // four surplus ones repeat pieces 0..3: same bytes to the same place), so "stage gs + 1 has landed" is the literal s_waitcnt
-  // vmcnt(2 * (KB_RING - 2)) -- loads are retired in order, other loads in flight only make the wait longer.
+  // four surplus ones repeat pieces 0..3: same bytes to the same place), so "stages gs + 1 and gs + 2 have landed" is the literal s_waitcnt
+  // vmcnt(2 * (KB_RING - 3)) -- loads are retired in order, other loads in flight only make the wait longer.
   const int total_stages = a.nlayers * 24;
   auto issue = [&](int gs) {
     if (gs >= total_stages) return;
@@ -142,40 +142,77 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   for (int gs = 0; gs < KB_RING - 1; ++gs) issue(gs);
   int gs0 = 0;                                     // first stage of the conv about to run
   // ---- one 64 -> 64 3x3 convolution of X: acc (accumulator layout) = W * X; returns with every wave past the last barrier
+  // Fragments are read ONE STAGE AHEAD: at the barrier that closes stage gs the B fragments (X, static during a conv) and the first slab's
+  // A fragments of stage gs + 1 are already in registers, so the first nine MFMAs of a stage start right behind the barrier and the second
+  // slab's A reads return under them (before: eighteen ds_read_b128 behind every barrier, their LDS latency exposed 192 times).  For the A
+  // fragments of stage gs + 1 to be readable DURING stage gs, the barrier that closes stage gs - 1 publishes stage gs + 1 as well: the wait in
+  // front of it leaves 2 * (KB_RING - 3) pieces in flight instead of 2 * (KB_RING - 2).
   auto conv = [&](f32x16 (&acc)[2]) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    // X complete (this wave's LDS stores) and stage gs0 landed (this wave's pieces; the barrier publishes the others')
+    auto x_base = [&](int s) {
+      const int chunk = s / 3, dx = s - chunk * 3;
+      return x_lds + chunk * KB_CHUNK + pxo + ((dx - 1) - KB_W) * 32 + lhi * 16;
+    };
+    auto w_base = [&](int gs) { return w_lds + (gs % KB_RING) * KB_WSTAGE + lane16; };
+    // X complete (this wave's LDS stores) and stages gs0, gs0 + 1 landed (this wave's pieces; the barrier publishes the others')
     KB_TADD(kq_rest);
-    if (gs0 + KB_RING - 1 <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 2)) & 15) | 0x0070);
+    if (gs0 + KB_RING - 1 <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 3)) & 15) | 0x0070);
     else __builtin_amdgcn_s_waitcnt(0x0070);
     asm volatile("s_barrier" ::: "memory");
     KB_TADD(kq_wait);
-    for (int s = 0; s < 12; ++s) {
-      const int gs = gs0 + s;
-      const char* const wb = w_lds + (gs % KB_RING) * KB_WSTAGE + lane16;
-      issue(gs + KB_RING - 1);                     // into the buffer stage gs - 1 has just left (every wave is past its barrier)
-      const int chunk = s / 3, dx = s - chunk * 3;
-      const char* const xb = x_lds + chunk * KB_CHUNK + pxo + ((dx - 1) - KB_W) * 32 + lhi * 16;
+    h8 bh[3], bl[3], a0h[3], a0l[3];
+    {
+      const char* const xb = x_base(0);
+      const char* const wb = w_base(gs0);
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const h8 bh = *reinterpret_cast<const h8*>(xb + dy * (KB_W * 32));
-        const h8 bl = *reinterpret_cast<const h8*>(xb + KB_PLANE + dy * (KB_W * 32));
+        bh[dy] = *reinterpret_cast<const h8*>(xb + dy * (KB_W * 32));
+        bl[dy] = *reinterpret_cast<const h8*>(xb + KB_PLANE + dy * (KB_W * 32));
+        a0h[dy] = *reinterpret_cast<const h8*>(wb + (dy * 2 + 0) * 1024);
+        a0l[dy] = *reinterpret_cast<const h8*>(wb + (dy * 2 + 1) * 1024);
+      }
+    }
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          const h8 ah = *reinterpret_cast<const h8*>(wb + (mb * 6 + dy * 2 + 0) * 1024);
-          const h8 al = *reinterpret_cast<const h8*>(wb + (mb * 6 + dy * 2 + 1) * 1024);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mb], 0, 0, 0);
+    for (int s = 0; s < 12; ++s) {
+      const int gs = gs0 + s;
+      const char* const wb = w_base(gs);
+      issue(gs + KB_RING - 1);                     // into the buffer stage gs - 1 has just left (every wave is past its barrier)
+      h8 a1h[3], a1l[3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {             // second slab of THIS stage: under the first slab's MFMAs
+        a1h[dy] = *reinterpret_cast<const h8*>(wb + (6 + dy * 2 + 0) * 1024);
+        a1l[dy] = *reinterpret_cast<const h8*>(wb + (6 + dy * 2 + 1) * 1024);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l[dy], bh[dy], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[dy], bl[dy], acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h[dy], bh[dy], acc[0], 0, 0, 0);
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l[dy], bh[dy], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[dy], bl[dy], acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h[dy], bh[dy], acc[1], 0, 0, 0);
+      }
+      if (s + 1 < 12) {                            // next stage's B and first-slab A fragments (stage gs + 1 was published a barrier ago)
+        const char* const xb = x_base(s + 1);
+        const char* const wn = w_base(gs + 1);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          bh[dy] = *reinterpret_cast<const h8*>(xb + dy * (KB_W * 32));
+          bl[dy] = *reinterpret_cast<const h8*>(xb + KB_PLANE + dy * (KB_W * 32));
+          a0h[dy] = *reinterpret_cast<const h8*>(wn + (dy * 2 + 0) * 1024);
+          a0l[dy] = *reinterpret_cast<const h8*>(wn + (dy * 2 + 1) * 1024);
         }
       }
-      // stage gs + 1 landed (the 2 * (KB_RING - 2) pieces of the stages behind it may stay in flight; near the end of the stream
-      // fewer were issued: wait for all), then the barrier: this buffer is free, the next one visible
+      // stages gs + 1 and gs + 2 landed (the 2 * (KB_RING - 3) pieces of the stages behind them may stay in flight; near the end of the
+      // stream fewer were issued: wait for all), then the barrier: this stage's buffer is free, the next two are visible
       KB_TADD(kq_mma);
-      if (gs + KB_RING <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 2)) & 15) | 0x0070);
+      if (gs + KB_RING <= total_stages) __builtin_amdgcn_s_waitcnt(((2 * (KB_RING - 3)) & 15) | 0x0070);
       else __builtin_amdgcn_s_waitcnt(0x0070);
       asm volatile("s_barrier" ::: "memory");
       KB_TADD(kq_wait);
