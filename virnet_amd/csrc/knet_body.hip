@@ -236,11 +236,12 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
   };
 
   const float inv_hw = 1.f / (float)(a.h * a.w);
-  for (int li = 0; li < a.nlayers; ++li) {
+  // A layer's small parameters travel global -> registers -> LDS one layer AHEAD: requested behind the previous layer's conv1 (the loads are in
+  // flight under its epilogue and conv2, never the youngest entries of the vmcnt queue when a stage boundary waits), written to the LDS block
+  // at the top of their layer -- behind the barrier that ended the previous layer's CALayer, the block's last reader.
+  float pv[KB_PAR_PT];
+  auto request_params = [&](int li) {
     const virnet_knet_layer& L = a.L[li];
-    // this layer's small parameters: requested now (the loads are older than every weight piece issued from here on, so the waits inside
-    // conv() retire them), written to LDS behind conv1's last barrier -- where the previous layer's CALayer has long finished reading
-    float pv[KB_PAR_PT];
 #pragma unroll
     for (int i = 0; i < KB_PAR_PT; ++i) {
       const int j = i * 512 + tid;
@@ -255,13 +256,16 @@ __global__ __launch_bounds__(512, 2) void knet_body_kernel(const KnetArgs a) {
       else if (j < KB_PAR_FLOATS) src = j - KB_PAR_CAW2 < 64 * a.cr ? L.caw2 + (j - KB_PAR_CAW2) : nullptr;
       pv[i] = src ? *src : 0.f;
     }
+  };
+  request_params(0);
+  for (int li = 0; li < a.nlayers; ++li) {
+#pragma unroll
+    for (int i = 0; i < KB_PAR_PT; ++i)
+      if (i * 512 + tid < KB_PAR_FLOATS) par[i * 512 + tid] = pv[i];          // (published by conv1's barriers)
     put_split(cur);
     f32x16 t[2];
     conv(t);                                                          // KNet.py:32
-#pragma unroll
-    for (int i = 0; i < KB_PAR_PT; ++i)
-      if (i * 512 + tid < KB_PAR_FLOATS) par[i * 512 + tid] = pv[i];
-    __syncthreads();
+    if (li + 1 < a.nlayers) request_params(li + 1);
     scale_bias(t, par + KB_PAR_INV1, par + KB_PAR_B1);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
