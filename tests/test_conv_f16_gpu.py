@@ -228,6 +228,29 @@ def test_f16x3_stride2_down_conv(monkeypatch, cin, cout, h, w, n):
     assert maxerr(raw.cpu(), raw_d.cpu()) <= TOL
 
 
+def test_slab_grouping_rules_do_not_change_a_bit(monkeypatch):
+    """The launch-shape rules of under-filled launches regroup the 32-channel slabs of a workgroup (csrc/conv_f16.hip: a mixed 3 + 2 grouping
+    becomes one single-slab launch up to 256 workgroups; csrc/conv_f16_s2.hip: one slab per workgroup at <= 64 tiles): channels are
+    independent, so every grouping must give the SAME bits -- checked at the shapes of the single-image SISR forward that the rules target."""
+    # 160 -> 160 stride-1 at 128 x 128: 128 tiles x (3 + 2 slabs) = 256 workgroups
+    cp = make_conv(160, 160, seed=62).cuda()
+    x = nhwc(rnd(1, 160, 128, 128, seed=63))
+    res = nhwc(rnd(1, 160, 128, 128, seed=64))
+    outs = []
+    for split in ("0", "256", "100000"):
+        monkeypatch.setenv("VIRNET_F16_SPLIT_WGS", split)
+        outs.append(ops.conv_mfma(x, cp.packed(), in_slope=0.2, res=res, want_raw=True)[0])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    monkeypatch.delenv("VIRNET_F16_SPLIT_WGS")
+    # 160 -> 224 stride-2 onto 64 x 64: 32 tiles
+    cp2 = make_conv(160, 224, stride=2, seed=65).cuda()
+    outs = []
+    for tiles in ("0", "64", "100000"):
+        monkeypatch.setenv("VIRNET_S2_SPLIT_TILES", tiles)
+        outs.append(ops.conv_mfma(x, cp2.packed(), stride=2, want_raw=True)[0])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 class ops_timer:
     """Context manager: route the launches through ops.LaunchTimer to see which kernel form ran."""
     def __enter__(self):
