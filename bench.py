@@ -203,7 +203,7 @@ def run_config(extra, timeout=420):
     return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
             "dtype": d["dtype"], "workload": d["config"]["workload"], "cmd": "bench.py " + " ".join(extra),
             "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "avg_launch_ms",
-                                               "launches_per_step", "share_of_conv_time")} if r else None,
+                                               "launches_per_step", "share_of_conv_time", "groups")} if r else None,
             "power": d.get("power")}
 
 
@@ -399,7 +399,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         ops.set_launch_timer(timer)     # two event records per conv launch, on the launch stream (~us of host time each)
-        with (PowerSampler(dev.index) if rank == 0 else _Null()) as psamp:
+        with PowerSampler(dev.index) as psamp:                # (every rank samples ITS device: a throttling rank must be visible in `multi_gpu.per_rank`)
             t0 = time.perf_counter()
             c0 = time.thread_time()
             for _ in range(args.steps):
@@ -411,7 +411,7 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
         ops.set_launch_timer(None)
-        power = psamp.summary() if rank == 0 else None
+        power = psamp.summary()
         # what ONE step costs the host with an empty launch queue (all ranks at once: N processes share the host's cores) -- the
         # number a rank's device time per step must exceed for the rank not to be host-bound
         # (measured with the range guard's end-of-forward flag read switched off for these three steps: the read waits for the device)
@@ -432,6 +432,27 @@ def main():
                 os.environ["VIRNET_RANGE_GUARD"] = guard_env
         torch.cuda.synchronize()
         host_one_step = sorted(one)[1]
+        # The headline's guard mode is --guard (default deferred, the mode of pipelined callers); the OTHER mode -- sync is the product default,
+        # engine.guard_check_mode -- is timed right behind it on the same box, same K steps, so that the line carries both
+        other_guard = None
+        if not training and world == 1 and not args.no_configs:
+            og = "sync" if args.guard == "deferred" else "deferred"
+            os.environ["VIRNET_GUARD_CHECK"] = og
+            try:
+                for _ in range(3):
+                    fwd(x)
+                engine.guard_poll()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    mu = fwd(x)[0]
+                torch.cuda.synchronize()
+                engine.guard_poll()
+                el_o = time.perf_counter() - t1
+            finally:
+                os.environ["VIRNET_GUARD_CHECK"] = args.guard
+            other_guard = {"mode": og, "value": round(batch * args.steps / el_o, 2), "ms_per_step": round(el_o / args.steps * 1e3, 3), "steps": args.steps,
+                           "note": f"the same K steps with VIRNET_GUARD_CHECK={og}, timed right behind the headline region (which ran with {args.guard})"}
         # A second, longer region (the contract's K steps are ~0.4 s: short against the firmware's power averaging and the box-to-box
         # spread): >= 50 steps when that stays under ~5 s.  Reported beside `value`, never instead of it.
         steady = None
@@ -460,7 +481,8 @@ def main():
                 "images_per_s": round((b - a) * args.steps / elapsed_local, 2), "seconds": round(elapsed_local, 4),
                 "host_ms_one_step_empty_queue": round(host_one_step * 1e3, 3),
                 "enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3), "host_cpu_ms_per_step": round(host_cpu / args.steps * 1e3, 3),
-                "cpu_threads": torch.get_num_threads()}
+                "cpu_threads": torch.get_num_threads(),
+                "power": ({k: power.get(k) for k in ("socket_w_mean", "socket_w_max", "cap_w", "sclk_mhz_mean", "sclk_mhz_min", "samples")} if power else None)}
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, mine)
         try:
@@ -526,6 +548,12 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "flop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                     "flop_unit": "GFLOP (2*MAC of the direct 3x3 convolution, algorithmic: SURVEY.md 8d)",
                     "share_of_conv_time": round(d["ms"] / total_ms, 4),
+                    # the launch groups of this workload by time (a group = every launch of one kernel family at one output-channel count, whatever
+                    # its epilogue / pre-activation instantiation): `kernel` above is groups[0] among the stride-1 3x3 convs
+                    "groups": [{"group": kname(k), "ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
+                                "share_of_conv_time": round(v["ms"] / total_ms, 4),
+                                "frac_algorithmic": (round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / FORMS[k[0]][1], 4) if k[0] in FORMS and v["ms"] > 0 else None)}
+                               for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:4]],
                     "by_kernel_ms_per_step": {kname(k): round(v["ms"] / args.steps, 3) for k, v in sorted(summ.items(), key=lambda kv: str(kv[0]))}}
     if world > 1:
         torch.distributed.barrier()
@@ -562,6 +590,7 @@ def main():
             "roofline": roof,
             "power": power,
             "steady_state": steady,
+            "other_guard_mode": other_guard,
             "multi_gpu": diag,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or sisr or training) else cpu_baseline(sd, args.size),
         }
@@ -581,7 +610,9 @@ def main():
             val = lambda d: d.get("value") if isinstance(d, dict) else None        # noqa: E731
             out["summary"] = {"unit": "images/s, one MI355X", "fwd256_x32": out["value"], "fwd128_x64": val(cf[0]), "sisr_x4_x16": val(cf[1]),
                               "train_bf16": val(cf[2]), "train_f32class": val(cf[3]), "sisr_train": val(cf[4]), "fwd256_x256_global": val(cf[5]),
-                              "roofline_frac_algorithmic": (roof or {}).get("frac_algorithmic"), "socket_w_mean": (power or {}).get("socket_w_mean")}
+                              "roofline_frac_algorithmic": (roof or {}).get("frac_algorithmic"), "socket_w_mean": (power or {}).get("socket_w_mean"),
+                              "guard": {args.guard: out["value"], (other_guard or {}).get("mode", "other"): (other_guard or {}).get("value"),
+                                        "headline_mode": args.guard, "product_default": "sync"}}
         if out["summary"] is None:
             out["summary"] = {"unit": out["unit"], "value": out["value"], "n_gpus": world, "roofline_frac_algorithmic": (roof or {}).get("frac_algorithmic")}
         print(json.dumps(out), flush=True)

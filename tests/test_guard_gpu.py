@@ -235,3 +235,30 @@ def test_eager_deferred_guard_poisons_then_repairs_in_place(monkeypatch):
         assert len(engine._pending_list()) <= engine.MAX_PENDING
         engine.guard_poll()
         assert not engine._pending_list()
+
+
+def test_deferred_repair_happens_before_the_warning_and_on_the_forward_s_stream(monkeypatch):
+    """(b) with a warning filter that RAISES the exception escapes from the settling call, but the overflowed forward's
+    outputs are already repaired; (c) the repair runs on the stream the forward was enqueued on, not on whatever is current at
+    settle time; (a) the pinned buffers are per thread."""
+    monkeypatch.setenv("VIRNET_GUARD_CHECK", "deferred")
+    net = _net()
+    x = synth_images(1, 3, 64, 64).cuda()
+    xh = _hot(x)
+    with torch.no_grad():
+        with ops.forward_scope(form=engine.FP32_FORM):
+            ref_hot = [t.clone() for t in engine._denoise_forward(net, xh)]
+        engine.guard_poll()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            mu, sig = net(xh)
+        assert engine._pending_list()[-1][5] == side
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            with pytest.raises(engine.RangeOverflowRepaired):
+                engine.guard_poll()                            # settles on the DEFAULT stream's thread context
+        side.synchronize()
+        assert torch.equal(mu, ref_hot[0]) and torch.equal(sig, ref_hot[1])
+        assert not engine._pending_list()
+    assert isinstance(engine._pinned_pool(), list) and not hasattr(engine, "_PINNED_POOL")

@@ -229,27 +229,38 @@ def _pending_list() -> list:
 
 def _settle(block: bool, keep: int = 0) -> None:
     """Look at the deferred forwards of this thread, oldest first: those whose flag copy has landed (all but `keep` of them when
-    `block`) are checked and, if they overflowed, repaired in place."""
+    `block`) are checked and, if they overflowed, repaired in place -- on the STREAM the forward ran on (the repair's writes are then
+    ordered behind that forward's own kernels and in front of whatever the caller enqueues on that stream next; a consumer on another
+    stream has to order itself against that stream as it had to for the forward itself).  The repair comes FIRST and the warning after
+    it: under ``-W error`` (or any filter that raises) the exception still escapes from this call, but the outputs it is about are
+    already correct."""
     import warnings
     pend = _pending_list()
     while pend:
-        pinned, ev, run, outs, dev = pend[0]
+        pinned, ev, run, outs, dev, stream = pend[0]
         if not ev.query():
             if not block or len(pend) <= keep:
                 return
             ev.synchronize()
         pend.pop(0)
-        _PINNED_POOL.append(pinned)
-        if int(pinned[0]):
-            warnings.warn(_GUARD_WARNING + " (deferred check: its outputs were NaN until now)", RangeOverflowRepaired, stacklevel=4)
+        overflowed = bool(int(pinned[0]))
+        _pinned_pool().append(pinned)
+        if overflowed:
             _GUARD_STATS["reruns"] += 1
-            with torch.no_grad(), torch.cuda.device(dev), ops.forward_scope(form=FP32_FORM):
+            with torch.no_grad(), torch.cuda.device(dev), torch.cuda.stream(stream), ops.forward_scope(form=FP32_FORM):
                 res = run()
-            for o, r in zip(outs, res if isinstance(res, tuple) else (res,)):
-                o.copy_(r)
+                for o, r in zip(outs, res if isinstance(res, tuple) else (res,)):
+                    o.copy_(r)
+            warnings.warn(_GUARD_WARNING + " (deferred check: its outputs were NaN until now)", RangeOverflowRepaired, stacklevel=4)
 
 
-_PINNED_POOL: list = []
+def _pinned_pool() -> list:
+    """Pinned one-int buffers of the calling thread's deferred checks (thread-local like the pending list: a process-global pool was a
+    check-then-pop race between two host threads)."""
+    pool = getattr(nat.tls, "guard_pinned", None)
+    if pool is None:
+        pool = nat.tls.guard_pinned = []
+    return pool
 
 
 def guard_poll(block: bool = True) -> None:
@@ -278,11 +289,12 @@ def _range_guarded(run, x: Tensor):
         outs = out if isinstance(out, tuple) else (out,)
         for o in outs:
             ops.poison_on_flag(flag, o)
-        pinned = _PINNED_POOL.pop() if _PINNED_POOL else torch.zeros(1, dtype=torch.int32).pin_memory()
+        pool = _pinned_pool()
+        pinned = pool.pop() if pool else torch.zeros(1, dtype=torch.int32).pin_memory()
         pinned.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        _pending_list().append((pinned, ev, run, outs, x.device))
+        _pending_list().append((pinned, ev, run, outs, x.device, torch.cuda.current_stream()))
         _settle(block=True, keep=MAX_PENDING)
     elif guarded and ops.range_overflowed(x.device):
         warnings.warn(_GUARD_WARNING, RuntimeWarning, stacklevel=3)

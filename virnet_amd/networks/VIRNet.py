@@ -15,7 +15,7 @@ from .AttResUNet import AttResUNet
 from .DnCNN import DnCNN
 from .KNet import KernelNet as KNet
 from .. import engine
-from ..graph import GraphedForward
+from ..graph import GraphedForward, auto_forward
 
 log_max = log(1e2)    # VIRNet.py:15
 log_min = log(1e-10)  # VIRNet.py:16
@@ -41,7 +41,8 @@ class VIRAttResUNet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .. import train
             return train.denoise_forward_autograd(self, x)
-        return engine.denoise_forward(self, x)
+        # inference: eager for the first calls of a shape, then replayed from a captured hipGraph (graph.auto_forward; VIRNET_AUTOGRAPH=0: always eager)
+        return auto_forward(self, engine.denoise_forward, x)
 
     def graphed(self, check: str = "sync") -> GraphedForward:
         """hipGraph-replayed forward for the one-image-per-call script path; outputs are reused buffers (see GraphedForward: range guard
@@ -71,7 +72,7 @@ class VIRAttResUNetSR(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .. import train_sisr
             return train_sisr.sisr_forward_train(self, x, sf)
-        return engine.sisr_forward(self, x, sf)
+        return auto_forward(self, engine.sisr_forward, x, sf, scale=int(sf) if isinstance(sf, (int, float)) and sf >= 1 else 1)
 
     def graphed(self, check: str = "sync") -> GraphedForward:
         """hipGraph-replayed forward: `g = net.graphed(); mu, kinfo, sigma = g(x, sf)`."""

@@ -69,6 +69,12 @@ class ConvParam(nn.Module):
             self._thin_key = key
         return self._thin
 
+    def _apply(self, fn, *args, **kwargs):
+        # Module.to() / .cuda() / .cpu() replace ``param.data`` without touching ``_version``: tell the captured graphs (graph._EPOCH)
+        from .. import graph
+        graph.bump_epoch()
+        return super()._apply(fn, *args, **kwargs)
+
     def invalidate(self) -> None:
         """Drop the cached packings.  They follow the parameter's storage and ``_version``; a write through ``.data`` (EMA helpers,
         weight clipping) changes neither, so call this (or ``net.apply(lambda m: getattr(m, 'invalidate', lambda: None)())``) after one."""

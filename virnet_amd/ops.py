@@ -107,7 +107,7 @@ DEFAULT_CONV_FORM = "wx4"
 # ---- per-forward snapshot of the environment knobs and the stream handle.  A single-image forward is ~45-100 launches and is bound by
 # the host: 340 os.environ lookups and one torch.cuda.current_stream() per launch were a fifth of it (tools/probes/host_profile.py).
 _KNOBS = ("VIRNET_BIAS_FUSED", "VIRNET_ENTRY_FUSED", "VIRNET_T_EMIT", "VIRNET_WX4_EMIT_ROWS", "VIRNET_WX4_ROWS", "VIRNET_CONV_FORM", "VIRNET_WINOGRAD", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS", "VIRNET_WX4_MIN_SLAB_WGS",
-          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM", "VIRNET_SFT_MULTI")
+          "VIRNET_RANGE_GUARD", "VIRNET_WGRAD_FORM", "VIRNET_DETERMINISTIC", "VIRNET_KNET_PERSISTENT", "VIRNET_EXIT_FORM", "VIRNET_SFT_MULTI", "VIRNET_ENTRY_FORM", "VIRNET_GUARD_CHECK", "VIRNET_AUTOGRAPH", "VIRNET_AUTOGRAPH_MAX_PIXELS", "VIRNET_AUTOGRAPH_MAX_GRAPHS")
 class forward_scope:
     """`with ops.forward_scope():` -- the knobs above and the launch stream are read once and held for the block (engine.py wraps every
     inference forward; outside a scope each op reads the environment itself, which is what the kernel-level tests rely on).  The

@@ -447,14 +447,18 @@ class _swapped_parameters:
             self.slots.append((mods[owner]._parameters, leaf, view))
 
     def __enter__(self):
+        from . import graph
         self.saved = [(d, leaf, d[leaf]) for d, leaf, _ in self.slots]
         for d, leaf, view in self.slots:
             d[leaf] = view
+        graph.bump_epoch()               # (writes into Module._parameters fire no registration hook: captured graphs re-validate)
         return self
 
     def __exit__(self, *exc):
+        from . import graph
         for d, leaf, p in self.saved:
             d[leaf] = p
+        graph.bump_epoch()
         return False
 
 
