@@ -169,6 +169,10 @@ int virnet_pack_f16_convt_weight(const float* w_iohw, int cout, int cin, float* 
 size_t virnet_wx4_weight_floats(int cin_pad, int n_pad);
 int virnet_pack_wx4_weight(const float* w_oihw, int dgrad, int cout, int cin, int cin_pad, int n_pad, float* packed, void* stream);
 int virnet_conv_wx4(const virnet_conv_desc* d, void* stream);
+/* What the calling thread's most recent virnet_conv_wx4 / virnet_conv_wx4_emit call launched (the library picks the tile form per launch
+ * size, csrc/conv_f16_wx4.hip): out[0] = tile rows of its first launch (16: conv_f16_wx4.hip / conv_f16_wx4p.hip, 8: conv_f16_wx4h.hip),
+ * out[1] = 1 when that launch was the persistent form (VIRNET_WX4_PERSIST=1), out[2] = 32-channel slabs per workgroup, out[3] = launches. */
+void virnet_conv_wx4_last_plan(int* out4);
 
 /* Few-output-channel exits with planar store (csrc/conv_exit.hip): AttResUNet.tail + crop + `+ x_in` (AttResUNet.py:139,173),
  * DnCNN.conv_last + exp(clamp) (DnCNN.py:29,41; VIRNet.py:43), KernelNet.tail (KNet.py:49) -- for cout * 9 <= 32 the (channel, tap) pairs

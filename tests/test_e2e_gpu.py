@@ -266,3 +266,28 @@ def test_real_config_cbsd_size_and_sisr_odd_lr(manifest):
         mu_s, k_s, s_s = snet(xl.cuda(), 3)
     assert mu_s.shape == (2, 3, 69, 51) and float((mu_s.cpu() - mu_r).abs().max()) <= TIGHT
     assert float((k_s.cpu() - k_r).abs().max()) <= 1e-5 and float((s_s.cpu() - s_r).abs().max()) <= 1e-5
+
+
+def test_entry_form_knob_is_honoured_inside_the_engine(manifest, monkeypatch):
+    """VIRNET_ENTRY_FORM was read through ops._env() but missing from the forward scope's snapshot, so every engine forward took
+    the default whatever the environment said.  The launch timer names the kernel that really ran."""
+    from virnet_amd import ops
+    net, _, _, _ = get_net(manifest, "syn")
+    x = synth_images(1, 3, 32, 32).cuda()
+
+    def kinds():
+        t = ops.LaunchTimer()
+        ops.set_launch_timer(t)
+        try:
+            with torch.no_grad():
+                out = net(x)
+        finally:
+            ops.set_launch_timer(None)
+        return {k[0][0] for k in t.records}, out
+
+    monkeypatch.delenv("VIRNET_ENTRY_FORM", raising=False)
+    k_def, a = kinds()
+    monkeypatch.setenv("VIRNET_ENTRY_FORM", "f16")
+    k_f16, b = kinds()
+    assert "entry" in k_def and "entry" not in k_f16
+    assert float((a[0] - b[0]).abs().max()) <= 2e-5 * max(1.0, float(a[0].abs().max()))

@@ -35,6 +35,8 @@ def _forms(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("VIRNET_CONV_FORM", "wx4")
     monkeypatch.setenv("VIRNET_DETERMINISTIC", "1")      # (single small images: keep them on the Winograd form, one tile height)
+    monkeypatch.setenv("VIRNET_AUTOGRAPH", "0")          # (this file is about the EAGER forward's guard and the explicit net.graphed(); the automatic
+                                                         #  replay of repeated shapes has its own file, tests/test_autograph_gpu.py)
 
 
 def test_graph_replay_is_range_guarded_sync():

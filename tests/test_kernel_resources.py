@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "virnet_amd", "csrc")
-HOT = ["conv_f16_wx4", "conv_f16_wx4h", "conv_f16", "conv_f16_s2", "conv_f16_pw", "conv_exit", "conv_entry", "wgrad_f16", "knet_body"]
+HOT = ["conv_f16_wx4", "conv_f16_wx4p", "conv_f16_wx4h", "conv_f16", "conv_f16_s2", "conv_f16_pw", "conv_exit", "conv_entry", "wgrad_f16", "knet_body"]
 
 # (unit, kernel regex) -> scratch bytes per lane tolerated, with the reason.  Everything else: zero.
 ALLOWED = [

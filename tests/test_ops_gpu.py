@@ -549,3 +549,28 @@ def test_conv_entry_abi_rejects_bad_descriptors():
     assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent(c0=6, ev=3)), st) != 0              # more than 8 record channels
     assert lib.virnet_conv_f16_entry(C.byref(desc()), C.byref(ent(ev=2)), st) != 0                    # vector channels without a vector
     torch.cuda.synchronize()
+
+
+def test_conv_entry_image_packed_for_another_channel_count_is_loud():
+    """slot j = dx*cin + ch is baked into virnet_pack_entry_weight's image and the host cannot look into device memory --
+    the image carries a trailer (cin, k-steps per row) that the kernel compares with the launch's channel count: a mismatch gives NaN,
+    not a plausible picture.  (ops.conv_entry checks pw.cin_real itself; this is the raw C-ABI caller.)"""
+    import ctypes as C
+    lib = nat.load()
+    cp3, cp4 = make_conv(3, 64, seed=5).cuda(), make_conv(4, 64, seed=6).cuda()
+    x = rnd(1, 3, 8, 8, seed=7, lo=0.0, hi=1.0).cuda()
+    y = torch.zeros(1, 8, 8, 64, device="cuda")
+    def call(pw):
+        d = nat.ConvDesc(x=nat.ptr(x), wpack=nat.ptr(pw.entry), bias=nat.ptr(pw.bias), res=0, mul=0, add=0, mask=0, mask_slope=0.0, in_mul=0, in_add=0,
+                         y_raw=nat.ptr(y), y_act=0, n=1, h=8, w=8, cin_pad=16, cout=64, n_pad=64, nrep=pw.nrep, ks=3, stride=1, epi=nat.EPI_NHWC,
+                         nchw_op=0, crop_h=0, crop_w=0, res_sf=1, in_act=0, in_slope=0.0, slope=0.2, clamp_lo=0.0, clamp_hi=0.0)
+        e = nat.PackDesc(x=nat.ptr(x), vec=0, map=0, out=0, n=1, c0=3, h=8, w=8, sf=1, ev=0, em=0, mh=0, mw=0, msf=1, map_sqrt=0, hp=8, wp=8, zero_pad=0)
+        assert lib.virnet_conv_entry(C.byref(d), C.byref(e), nat.stream_handle()) == 0
+        torch.cuda.synchronize()
+        return y.clone()
+    good = call(cp3.packed())
+    assert bool(torch.isfinite(good).all()) and float(good.abs().max()) > 0
+    bad = call(cp4.packed())                                  # packed for 4 input channels, launched with 3
+    assert bool(torch.isnan(bad).all())
+    tr = cp3.packed().entry[-4:].view(torch.int32).tolist()
+    assert tr[:3] == [3, 1, 64]

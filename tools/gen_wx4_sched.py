@@ -162,6 +162,32 @@ def build(nrep, ji, pre):
     return ops, nm
 
 
+def build_first0(nrep, pre):
+    """stage 0 of an item's FIRST chunk in the persistent kernel: positions {2,5} are in V already (stored by the previous epilogue, or by
+    the workgroup's prologue), so the stage only multiplies, moves weights and requests the next chunk's pixels"""
+    ng, nm = 3 * nrep, 9 * nrep
+    ndi = (12 * nrep + 7) // 8
+    ops = []
+    reads = []
+    for dy in range(3):
+        reads.append(("rdB%d" % dy, "rdB(%s);" % I(dy), 3 * nrep * dy))
+    for g in range(ng):
+        reads.append(("rdA%d" % g, "rdA(%s);" % I(g), first_use(g, nrep)))
+    for name, code, use in sorted(reads, key=lambda r: r[2]):
+        o = Op(name, code, 2, kind="ldsr")
+        o.deadline = max(0, use - LDS_LAT)
+        ops.append(o)
+    dma = [Op("dma%d" % i, "dma(%s);" % I(i), 4, kind="dma") for i in range(ndi)]
+    for i, d in enumerate(dma):
+        d.earliest = 1 + i
+    lds = []
+    for b in range(6):
+        lds.append(Op("ldp%d" % b, "ldp(%s);" % I(b), 3, [(d.name, 0) for d in dma], kind="vmem"))
+    for b in range(6):
+        lds.append(Op("ldh%d" % b, "ldh(%s);" % I(b), 3, [("ldp5", 0)] + [(d.name, 0) for d in dma], kind="vmem"))
+    return ops + dma + lds, nm
+
+
 def build_final(nrep, ji):
     """stages of the LAST chunk: there is no next chunk to stage, so stage 0 only finishes positions {2,5} (+ halo pair 2), stages 1 and 2
     only read and multiply, and stage 2 -- whose weights' successor does not exist either -- requests the epilogue's first operand tile
@@ -226,14 +252,19 @@ def schedule(ops, nm):
     return load
 
 
-def emit(nrep, ji, pre, out):
-    if pre is None:
+def emit(nrep, ji, pre, out, kind=None):
+    if kind == "first0":
+        ops, nm = build_first0(nrep, pre)
+    elif pre is None:
         ops, nm = build_final(nrep, ji)
     else:
         ops, nm = build(nrep, ji, pre)
     load = schedule(ops, nm)
     order = {"ldsr": 0, "ldsr2": 0, "dma": 1, "vmem": 2, "valu": 3, "ldsw": 4}
-    out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre) if pre is not None else "#define WX4_FINAL_%d_%d \\" % (nrep, ji))
+    if kind == "first0":
+        out.append("#define WX4_STAGE0F_%d_%d \\" % (nrep, pre))
+    else:
+        out.append("#define WX4_STAGE_%d_%d_%d \\" % (nrep, ji, pre) if pre is not None else "#define WX4_FINAL_%d_%d \\" % (nrep, ji))
     for s in range(nm + 1):
         here = sorted([o for o in ops if o.slot == s], key=lambda o: order[o.kind])
         line = "  SB(); " + " ".join(o.code for o in here) + " SB();"
@@ -255,6 +286,11 @@ def main():
             for pre in (0, 1, 2):
                 emit(nrep, ji, pre, out)
             emit(nrep, ji, None, out)
+    # the persistent kernel's extra stage form (conv_f16_wx4p.hip): three-slab workgroups, PRE 0 / 1
+    out.append("// WX4_STAGE0F_<NREP>_<PRE>: first stage of an item in conv_wx4p_kernel (positions {2,5} of its first chunk are in V already)")
+    out.append("")
+    for pre in (0, 1):
+        emit(3, 0, pre, out, kind="first0")
     sys.stdout.write("\n".join(out) + "\n")
 
 

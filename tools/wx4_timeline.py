@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="l0")
     ap.add_argument("--mode", default="pre")
+    ap.add_argument("--loaded", type=int, default=0, help="launches in front of the stamped one, stamps on (the socket at its power cap: ~300)")
     args = ap.parse_args()
     n, h, w, c = SHAPES[args.shape]
     lib = nat.load()
@@ -39,6 +40,8 @@ def main():
         ops.conv_mfma(x, pw, **kw)
     torch.cuda.synchronize()
     lib.virnet_debug_timing_buffer(log.data_ptr())
+    for _ in range(args.loaded):
+        ops.conv_mfma(x, pw, **kw)
     ops.conv_mfma(x, pw, **kw)
     torch.cuda.synchronize()
     lib.virnet_debug_timing_buffer(None)

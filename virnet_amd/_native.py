@@ -106,6 +106,7 @@ SYMBOLS = [
     ("virnet_wx4_weight_floats", C.c_size_t, [C.c_int, C.c_int]),
     ("virnet_pack_wx4_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv_wx4", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    ("virnet_conv_wx4_last_plan", None, [C.POINTER(C.c_int)]),
     ("virnet_exit_weight_floats", C.c_size_t, [C.c_int]),
     ("virnet_pack_exit_weight", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     ("virnet_conv_exit", C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256, (NSLAB == 3 && NT == 2) ? 1 : 2) void conv_ent
 
   // ---- weights, scale / bias table, zero area: once per workgroup
   for (int i = tid * 16; i < WBYTES; i += 256 * 16) *reinterpret_cast<f32x4*>(w_lds + i) = *reinterpret_cast<const f32x4*>(a.wimg + i);
-  if (tid < NB) sb_lds[tid] = a.inv_scale[tid];
+  // (the image's trailer names the channel count it was packed for -- slot j = dx*cin + ch is baked into it: a caller of the C ABI that
+  // hands over an image packed for another count gets NaN, not a plausible picture; ADVICE r05.  The host cannot look: device memory.)
+  const bool img_ok = *reinterpret_cast<const int*>(a.wimg + WBYTES) == nchan && *reinterpret_cast<const int*>(a.wimg + WBYTES + 4) == NT;
+  if (tid < NB) sb_lds[tid] = img_ok ? a.inv_scale[tid] : __builtin_nanf("");
   else if (tid < 2 * NB) sb_lds[tid] = a.bias ? a.bias[tid - NB] : 0.f;
   if (tid < EN_ZERO) z_lds[tid] = 0.f;
 
@@ -325,7 +328,14 @@ __global__ void pack_entry_kernel(const float* __restrict__ w, int cout, int cin
     *reinterpret_cast<_Float16*>(img + base) = hi;
     *reinterpret_cast<_Float16*>(img + base + 1024) = (_Float16)(v - (float)hi);
   }
+  if (row == 0 && threadIdx.x == 0) {                      // trailer behind the image: what it was packed for (checked by the kernel)
+    int* const tr = reinterpret_cast<int*>(img + (size_t)3 * nt * nslab * 2048);
+    tr[0] = cin; tr[1] = nt; tr[2] = n_pad; tr[3] = 0x454e5452;      // 'ENTR'
+  }
 }
+
+// what the launcher asks the runtime once per (device, dynamic LDS size), not per launch (the single-image path is host-bound)
+struct EntryOcc { int lds = -1, occ = 0, n_cu = 0; };
 
 template <int NSLAB, int NT>
 int launch_entry(FArgs k, int nchan, hipStream_t st) {
@@ -337,16 +347,21 @@ int launch_entry(FArgs k, int nchan, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return virnet::set_error("hipFuncSetAttribute(conv_entry): %s", hipGetErrorString(e));
   }
-  // two persistent workgroups per CU (occupancy: registers / 76-90 KB of LDS), fewer when the XCD's tile range is shorter
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+  // two persistent workgroups per CU (occupancy: registers / 76-90 KB of LDS), fewer when the XCD's tile range is shorter.  Occupancy and
+  // CU count are cached per device (a box with mixed devices) and dynamic-LDS size; the knob is read per launch (A/B runs flip it in-process)
+  static thread_local EntryOcc cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  EntryOcc& c = cache[dev];
+  if (c.lds != lds) {
+    c.lds = lds;
+    if (hipDeviceGetAttribute(&c.n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c.n_cu <= 0) c.n_cu = 256;
+    // workgroups that really are co-resident on a CU (registers and this launch's LDS)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c.occ, kern, 256, (size_t)lds) != hipSuccess || c.occ <= 0) c.occ = 1;
   }
+  const int n_cu = c.n_cu;
   const char* const env = getenv("VIRNET_ENTRY_WGS_PER_CU");
-  int occ = 0;        // workgroups that really are co-resident on a CU (registers and this launch's LDS)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, (size_t)lds) != hipSuccess || occ <= 0) occ = 1;
-  const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(3, occ);
+  const int per_cu = env && atoi(env) > 0 ? atoi(env) : std::min(3, c.occ);
   const int wgs_per_xcd = std::max(1, std::min(k.tiles_per_xcd, per_cu * n_cu / 8));
   const virnet_pack_desc& e = k.ent;
   EntrySrc src{};
@@ -364,7 +379,7 @@ int launch_entry(FArgs k, int nchan, hipStream_t st) {
 
 extern "C" size_t virnet_entry_weight_floats(int cin, int n_pad) {
   const int nt = 3 * cin <= 16 ? 1 : 2;
-  return (size_t)n_pad + (size_t)3 * nt * (n_pad / 32) * 512;       // n_pad scales + [dy][t][slab] x 2 KB
+  return (size_t)n_pad + (size_t)3 * nt * (n_pad / 32) * 512 + 4;   // n_pad scales + [dy][t][slab] x 2 KB + trailer {cin, nt, n_pad, tag}
 }
 
 extern "C" int virnet_pack_entry_weight(const float* w, int cout, int cin, int n_pad, float* packed, void* stream) {

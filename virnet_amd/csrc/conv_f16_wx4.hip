@@ -871,6 +871,13 @@ extern "C" int virnet_pack_wx4_weight(const float* w, int dgrad, int cout, int c
 
 static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t_emit* te);
 
+// what the calling thread's most recent virnet_conv_wx4 / _emit call launched: {tile rows of its first launch (8 / 16), 1 if that launch was
+// the persistent form, slabs per workgroup of the first launch, number of launches}
+static thread_local int g_wx4_plan[4] = {0, 0, 0, 0};
+extern "C" void virnet_conv_wx4_last_plan(int* out) {
+  if (out) for (int i = 0; i < 4; ++i) out[i] = g_wx4_plan[i];
+}
+
 extern "C" int virnet_conv_wx4(const virnet_conv_desc* d, void* stream) { return conv_wx4_impl(d, stream, nullptr); }
 
 extern "C" int virnet_conv_wx4_emit(const virnet_conv_desc* d, const virnet_t_emit* te, void* stream) {
@@ -977,6 +984,10 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
   };
   const bool te8 = te && te->rows == 8;                    // emitting form: 16-row tiles (8 waves) or 8-row tiles (4 waves, two workgroups per CU)
   if (te) virnet::t_emit_args(k, te, d->w, d->cout, te8 ? d->n * ((d->h + 7) / 8) * ((d->w + 31) / 32) * 4 : d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * 8);
+  g_wx4_plan[0] = g_wx4_plan[1] = g_wx4_plan[2] = g_wx4_plan[3] = 0;
+  auto note = [&](int rows, int persistent, int nrep) {
+    if (g_wx4_plan[3]++ == 0) { g_wx4_plan[0] = rows; g_wx4_plan[1] = persistent; g_wx4_plan[2] = nrep; }
+  };
   auto run = [&](int nrep, int slab_base, int groups) -> int {
     if (groups <= 0) return 0;
     FArgs kk = k;
@@ -988,8 +999,9 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
     if (nrep == 3 && epi == 1 && pre == 0 && !te) return launch_wx4<3, 1, 0>(kk, st);
     return virnet::set_error("virnet_conv_wx4: ledger probe build (WX4_LEDGER=%d) has no kernel for nrep=%d epi=%d pre=%d", WX4_LEDGER, nrep, epi, pre);
 #else
-    if (te8) return virnet::launch_wx4h_emit(kk, nrep, epi, pre, st);
+    if (te8) { note(8, 0, nrep); return virnet::launch_wx4h_emit(kk, nrep, epi, pre, st); }
     if (te) {                                               // emission: the tile form the caller asked for, whatever the launch size
+      note(16, 0, nrep);
 #define VIRNET_WX4_TE(N_, E_) if (nrep == N_ && epi == E_) return pre == 1 ? launch_wx4<N_, E_, 1, 1>(kk, st) : launch_wx4<N_, E_, 0, 1>(kk, st);
 #define VIRNET_WX4_TEN(N_) VIRNET_WX4_TE(N_, 0) VIRNET_WX4_TE(N_, 1) VIRNET_WX4_TE(N_, 2) VIRNET_WX4_TE(N_, 3)
       VIRNET_WX4_TEN(3) VIRNET_WX4_TEN(2) VIRNET_WX4_TEN(1)
@@ -997,7 +1009,20 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
 #undef VIRNET_WX4_TE
       return virnet::set_error("virnet_conv_wx4_emit: no emitting kernel for nrep=%d epi=%d pre=%d", nrep, epi, pre);
     }
-    if (nrep == 5 || half_tiles_for(nrep, groups)) return virnet::launch_wx4h(kk, nrep, epi, pre, st);
+    if (nrep == 5 || half_tiles_for(nrep, groups)) { note(8, 0, nrep); return virnet::launch_wx4h(kk, nrep, epi, pre, st); }
+    // 16-row tiles, persistent form (conv_f16_wx4p.hip, round 6: one workgroup per CU walks its XCD's items, the next item's first chunk is
+    // staged by the last chunk's stages, the epilogue's exchange leaves V and weight buffer 0 alone).  BUILT, bit-identical, and measured:
+    // 12 % fewer cycles per tile under load (70.4 k against 80.1 k), and 2 % MORE time per launch / 1.7 % fewer images per second end to end --
+    // at the 1400 W cap the clock gives the cycles back (profiles/r06_probes.md 2).  Therefore opt-in: VIRNET_WX4_PERSIST=1, for launches of
+    // at least VIRNET_WX4_PERSIST_MIN (default 2) items per CU.
+    {
+      const char* const pe = getenv("VIRNET_WX4_PERSIST");
+      const char* const pm = getenv("VIRNET_WX4_PERSIST_MIN");
+      const long items = (long)d->n * ((d->h + 15) / 16) * ((d->w + 31) / 32) * groups;
+      if (pe && pe[0] == '1' && virnet::wx4p_serves(kk, nrep, epi, pre) && items >= (long)(pm ? atoi(pm) : 2) * n_cu && rows_pin != 8)
+        { note(16, 1, nrep); return virnet::launch_wx4p(kk, nrep, epi, pre, n_cu, st); }
+    }
+    note(16, 0, nrep);
 #define VIRNET_WX4_EPI(N_, E_)                                                                                               \
     if (epi == E_) return pre == 2 ? launch_wx4<N_, E_, 2>(kk, st) : pre == 1 ? launch_wx4<N_, E_, 1>(kk, st) : launch_wx4<N_, E_, 0>(kk, st);
 #define VIRNET_WX4_CASE(N_)                                                                              \

@@ -75,4 +75,8 @@ __device__ __forceinline__ float wx4_coef(int j, int b) {
 int launch_wx4h(FArgs k, int nrep, int epi, int pre, hipStream_t st);
 int launch_wx4h_emit(FArgs k, int nrep, int epi, int pre, hipStream_t st);   // TE = 1 instantiations (pre 0 / 1, epi 0..3)
 
+// the persistent, overlapped 16-row form (conv_f16_wx4p.hip; round 6): what it serves, and its launcher (`k` filled as for conv_wx4's own launch)
+bool wx4p_serves(const FArgs& k, int nrep, int epi, int pre);
+int launch_wx4p(FArgs k, int nrep, int epi, int pre, int n_cu, hipStream_t st);
+
 }  // namespace virnet

@@ -227,6 +227,14 @@ def pack_wx4_weight(weight: Tensor, *, dgrad: bool = False) -> Tensor:
     return out
 
 
+def wx4_last_plan() -> dict:
+    """What the calling thread's most recent Winograd-form convolution launched (virnet_conv_wx4_last_plan): tile rows of its first launch,
+    whether that was the persistent form, slabs per workgroup, number of launches."""
+    out = (C.c_int * 4)()
+    nat.load().virnet_conv_wx4_last_plan(out)
+    return {"rows": out[0], "persistent": bool(out[1]), "slabs": out[2], "launches": out[3]}
+
+
 def _wino_enabled() -> bool:
     return conv_form() == "wino"
 
