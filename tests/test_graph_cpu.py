@@ -93,3 +93,23 @@ def test_auto_forward_bypasses_for_cpu_tensors_and_inside_no_autograph():
     with graph.no_autograph():
         graph.auto_forward(m, fn, x, 4, scale=4)
     assert calls[-1][1] == (4,)
+
+
+def test_every_product_knob_is_listed_in_knobs_md():
+    """tools/knobs.md is the one table of the VIRNET_* knobs and launch-shape constants: every environment
+    variable the product reads -- Python (`_env`, os.environ) or library (`getenv`) -- has a row there."""
+    names = set()
+    pats = (r"_env\(\s*\"(VIRNET_[A-Z0-9_]+)\"", r"environ(?:\.get)?\s*[\[\(]\s*\"(VIRNET_[A-Z0-9_]+)\"", r"getenv\(\s*\"(VIRNET_[A-Z0-9_]+)\"")
+    files = glob.glob(os.path.join(REPO, "virnet_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(REPO, "virnet_amd", "csrc", "*.*")) + [os.path.join(REPO, "bench.py")]
+    for path in files:
+        if path.endswith((".py", ".hip", ".cpp", ".h")):
+            with open(path) as f:
+                src = f.read()
+            for p in pats:
+                names |= set(re.findall(p, src))
+    assert len(names) >= 40
+    with open(os.path.join(REPO, "tools", "knobs.md")) as f:
+        doc = f.read()
+    listed = set(re.findall(r"`(VIRNET_[A-Z0-9_]+)`", doc)) | {"VIRNET_FORCE" + s for s in ("_NREP", "_NW")}      # (one row: `VIRNET_FORCE_MREP` / `_NREP` / `_NW`)
+    missing = sorted(names - listed)
+    assert not missing, f"read by the product but not in tools/knobs.md: {missing}"

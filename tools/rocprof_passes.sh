@@ -19,7 +19,7 @@ rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_B
   --kernel-trace -d "$OUT/pmc_sq2" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" -o p --output-format csv -- $BENCH --steps 1 --warmup 1 --no-roofline > "$OUT/pmc_write.log" 2>&1
-python $ROOT/tools/summarize_r05.py "$OUT" "$OUT" $TAG > "$OUT/summary.txt" 2> "$OUT/summary.err"
+python $ROOT/tools/summarize_r06.py "$OUT" "$OUT" $TAG > "$OUT/summary.txt" 2> "$OUT/summary.err"
 tail -3 "$OUT/trace.log"; tail -5 "$OUT/summary.err"; cat "$OUT/summary.txt"; cp $(find "$OUT/trace" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"; find "$OUT" -name "*kernel_trace.csv" -size +4M -delete
 # keep gpurun_out small: drop the raw per-dispatch CSVs except the stats
 find "$OUT" -name "*counter_collection.csv" -size +8M -delete
