@@ -195,3 +195,23 @@ def test_two_host_threads_have_their_own_graphs():
         t.join()
     assert not errs, errs
     assert all(s["graphs"] == 1 and s["replays"] == 3 for s in stats), stats
+
+
+def test_a_knob_flipped_between_two_calls_of_one_shape_is_not_replayed_from_the_old_capture(monkeypatch):
+    """The captured launches bake in the knobs of capture time: the environment is part of the key (tests/test_e2e_gpu.py's
+    test_full_size_properties flips VIRNET_DETERMINISTIC between calls of one shape and found this)."""
+    net = _net()
+    x = synth_images(1, 3, 128, 128).cuda()
+    with torch.no_grad():
+        for _ in range(4):
+            a = net(x)[0]
+        assert graph.auto_stats(net)["replays"] == 2
+        monkeypatch.setenv("VIRNET_CONV_FORM", "f16x3")           # another kernel family: different low bits
+        with graph.no_autograph():
+            ref = net(x)[0].clone()
+        assert not torch.equal(ref, a)
+        for _ in range(4):
+            assert torch.equal(net(x)[0], ref)
+        assert graph.auto_stats(net)["graphs"] == 2
+        monkeypatch.delenv("VIRNET_CONV_FORM")
+        assert torch.equal(net(x)[0], a)                          # the first capture is still there for the first environment

@@ -20,6 +20,7 @@ def _form(monkeypatch):
     for k in ("VIRNET_WX4_MIN_TILES", "VIRNET_WX4_MIN_COUT", "VIRNET_WX4_MIN_FILL", "VIRNET_WX4_MIN_WGS"):
         monkeypatch.setenv(k, "0")
     monkeypatch.delenv("VIRNET_WINOGRAD", raising=False)
+    monkeypatch.setenv("VIRNET_WX4_NREP", "3")               # (three-slab workgroups also on launches that leave CUs empty: the form under test)
     monkeypatch.setenv("VIRNET_WX4_PERSIST", "1")            # (the form is opt-in: measured slower at the power cap, profiles/r06_probes.md 2)
 
 

@@ -19,6 +19,7 @@ Two things a captured graph must not do silently, and does not:
 from __future__ import annotations
 
 import operator
+import os
 import threading
 import warnings
 import weakref
@@ -56,6 +57,15 @@ torch.nn.modules.module.register_module_module_registration_hook(_bump)
 
 
 _CAPTURE_LOCK = threading.Lock()
+
+
+def _env_stamp() -> int:
+    """One hash over the process environment.  The captured launches bake in what every VIRNET_* knob said at capture time (kernel form,
+    tile height, store policy ... -- read by Python per forward and by the library per launch, tools/knobs.md), so the environment is part
+    of a graph's key: a test or a caller that flips a knob between two calls of the same shape gets a fresh capture, not the old form.
+    (The whole environment, not only VIRNET_*: 2 us for ~80 variables, against 9 us for filtering them.)"""
+    data = getattr(os.environ, "_data", None)
+    return hash(tuple(data.items())) if data is not None else hash(tuple(sorted(os.environ.items())))
 
 
 class RangeOverflow(RuntimeError):
@@ -151,7 +161,7 @@ class GraphedForward:
             self._graphs.clear()                      # parameters changed: the packed weights baked into the launches are stale
             self._seen.clear()
             self._stamp = stamp
-        key = (tuple(x.shape), x.device.index, args)
+        key = (tuple(x.shape), x.device.index, args, _env_stamp())
         hit = self._graphs.get(key)
         if hit is None:
             if self.auto_after > 0:
