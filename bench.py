@@ -14,8 +14,8 @@ plain command works as well as the torchrun one.
 
 ``--dry-run-topology`` (with ``--gpus N``): no timed steps -- every rank reports its device UUID, the run fails if two ranks share a device
 although enough are visible (virnet_amd.dist.rank_topology), and the start-up weight broadcast is timed on its own.  ``--guard sync|deferred``:
-how the timed inference forwards learn of an fp16-range overflow (engine.guard_check_mode; default deferred = no host wait per forward, every
-forward checked before the clock stops).  Defaults: 30 timed steps behind 10 warm-up steps (the socket needs ~0.2 s of load to settle at its cap).
+how the timed inference forwards learn of an fp16-range overflow (engine.guard_check_mode; default sync = the product's default: one flag
+read per forward; round 5's lines ran deferred -- the line carries BOTH modes' values, `summary.guard`, measured 1 584 / 1 570 img/s on one box).  Defaults: 30 timed steps behind 10 warm-up steps (the socket needs ~0.2 s of load to settle at its cap).
 
 Rank 0 prints ONE JSON line whose FIRST key, ``summary``, holds the seven headline values; besides the contract fields it carries
   roofline     : the dominant kernel = the launch group of the C->C 3x3 res-block convs with the most time (conv_f16_kernel by
@@ -432,8 +432,8 @@ def main():
                 os.environ["VIRNET_RANGE_GUARD"] = guard_env
         torch.cuda.synchronize()
         host_one_step = sorted(one)[1]
-        # The headline's guard mode is --guard (default deferred, the mode of pipelined callers); the OTHER mode -- sync is the product default,
-        # engine.guard_check_mode -- is timed right behind it on the same box, same K steps, so that the line carries both
+        # The headline's guard mode is --guard (default sync = the product default, engine.guard_check_mode); the OTHER mode (deferred: the mode of
+        # pipelined callers, round 5's headline) is timed right behind it on the same box, same K steps, so that the line carries both
         other_guard = None
         if not training and world == 1 and not args.no_configs:
             og = "sync" if args.guard == "deferred" else "deferred"

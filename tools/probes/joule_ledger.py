@@ -100,7 +100,7 @@ def main():
                     env = dict(os.environ, **extra)
                     if name != "shipped":
                         env["VIRNET_HIP_LIB"] = os.path.join(ROOT, "virnet_amd", "lib", f"libvirnet_hip_led_{name}.so")
-                    cmd = [sys.executable, os.path.abspath(__file__), "--shape", shape, "--mode", mode, "--seconds", str(a.seconds), "--tag", name]
+                    cmd = [sys.executable, os.path.abspath(__file__), "--shape", shape, "--mode", mode, "--seconds", str(a.seconds), "--tag", name, "--op", a.op]
                     out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
                     got = [json.loads(ln[7:]) for ln in out.stdout.splitlines() if ln.startswith("LEDGER ")]
                     if not got:

@@ -15,6 +15,9 @@
 // epilogue (per-wave LDS turn-around, loads before stores, buffer stores) follow conv_f16.hip; only the bias / single-store epilogue
 // exists here (the down conv has no residual, mask or SFT: AttResUNet.py:74).
 #include "conv_f16_common.h"
+#ifndef S2_LEDGER
+#define S2_LEDGER 0      // probe builds only (tools/build_ledger_s2.sh)
+#endif
 #include <cstdlib>
 #include <type_traits>
 
@@ -190,6 +193,16 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_s2_kernel(const FArgs a
         for (int nr = 0; nr < NREP; ++nr) {
           const h8 wa = (part == 0) ? al[cur][nr] : ah[cur][nr];
           const h8 xv = (part == 1) ? bl[dy] : bh[dy];
+#if S2_LEDGER
+          // probe builds (tools/build_ledger_s2.sh, profiles/r06_probes.md 6): 1 = no MFMA, 2 = two of the three products, 3 = one -- what the
+          // launch would cost with fewer products and everything else in place (the upper bound of a reduced-product form).  Never shipped.
+          if (S2_LEDGER == 1 || (S2_LEDGER == 2 && part == 0) || (S2_LEDGER == 3 && part != 2)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(wa), "v"(xv));
+#endif
+            continue;
+          }
+#endif
           acc[nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[nr], 0, 0, 0);
         }
       constexpr int NM = 3 * NREP;
