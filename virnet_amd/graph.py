@@ -52,8 +52,15 @@ def bump_epoch() -> None:
     _EPOCH[0] += 1
 
 
-torch.nn.modules.module.register_module_parameter_registration_hook(_bump)
-torch.nn.modules.module.register_module_module_registration_hook(_bump)
+_HOOKS = []
+
+
+def _install_hooks() -> None:
+    """The two global registration hooks, installed when the FIRST GraphedForward is built (at import every nn.Module
+    construction of the process paid the callback, whether or not a graph existed)."""
+    if not _HOOKS:
+        _HOOKS.append(torch.nn.modules.module.register_module_parameter_registration_hook(_bump))
+        _HOOKS.append(torch.nn.modules.module.register_module_module_registration_hook(_bump))
 
 
 _CAPTURE_LOCK = threading.Lock()
@@ -84,6 +91,7 @@ class GraphedForward:
                  check: str = "sync", auto_after: int = 0, fresh: bool = False, max_graphs: int = 0):
         if check not in ("sync", "deferred", "off"):
             raise ValueError(f"check={check!r}: expected 'sync', 'deferred' or 'off'")
+        _install_hooks()
         self.fn, self.warmup, self.check = fn, warmup, check
         self.auto_after, self.fresh, self.max_graphs = auto_after, fresh, max_graphs
         self._params = params
