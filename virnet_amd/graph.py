@@ -135,6 +135,7 @@ class GraphedForward:
             for _ in range(self.warmup):              # packs weights, sets kernel attributes, fills the allocator pool
                 self.fn(static_x, *args)
         torch.cuda.current_stream().wait_stream(side)
+        pinned = torch.zeros(1, dtype=torch.int32).pin_memory() if flag is not None else None
         graph = torch.cuda.CUDAGraph()
         # (thread_local: launches and allocations of OTHER host threads -- each with its own graphs, see auto_forward -- do not invalidate
         # this capture; captures themselves are serialised)
@@ -146,7 +147,9 @@ class GraphedForward:
             if flag is not None:
                 for o in out:
                     ops.poison_on_flag(flag, o)
-        pinned = torch.zeros(1, dtype=torch.int32).pin_memory() if flag is not None else None
+                if pinned is not None and self.check == "sync":
+                    pinned.copy_(flag, non_blocking=True)      # the flag travels to pinned memory as the graph's last node: the sync check
+                                                               # below waits for an event and reads host memory (no separate device -> host read)
         return graph, static_x, out, flag, pinned
 
     def poll(self) -> None:
@@ -190,14 +193,24 @@ class GraphedForward:
         static_x.copy_(x)
         graph.replay()
         self.replays += 1
-        ret = tuple(o.clone() for o in out) if self.fresh else out      # (enqueued behind the replay, in front of the host's flag read)
+        done = None
+        if flag is not None and self.check == "sync":
+            done = torch.cuda.Event()
+            done.record()                                    # behind the graph (whose last node copied the flag to pinned memory)
+        if self.fresh:                                       # fresh tensors, ONE copy launch (enqueued behind the replay; the host does not wait for it)
+            ret = tuple(torch.empty_like(o) for o in out)
+            torch._foreach_copy_(list(ret), list(out))
+        else:
+            ret = out
         if flag is not None:
             if self.check == "deferred":
                 pinned.copy_(flag, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 self._pending = (pinned, ev)
-            elif bool(flag.item()):
+                return ret if len(ret) > 1 else ret[0]
+            done.synchronize()
+            if int(pinned[0]):
                 warnings.warn("VIRNet HIP path: an activation left fp16's range in a replayed graph; this input was repeated eagerly "
                               "with the fp32 kernels", RuntimeWarning, stacklevel=2)
                 self.reruns += 1
