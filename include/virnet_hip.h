@@ -28,8 +28,10 @@ extern "C" {
 
 /* 2 (round 5): round 4's additions -- virnet_t_emit / virnet_knet_layer, the emitting and persistent entry points, the convT weight image
  * that keeps cin when cin % 32 == 0 -- were shipped under version 1; a stale library now fails the version check instead of an
- * AttributeError / a mis-sized packing. */
-#define VIRNET_ABI_VERSION 3
+ * AttributeError / a mis-sized packing.
+ * 4 (round 6): virnet_conv_wx4_last_plan; the packed entry image (virnet_pack_entry_weight / virnet_entry_weight_floats) carries a four-word
+ * trailer {cin, k-steps per row, n_pad, tag} that virnet_conv_entry's kernel checks against the launch (a mismatch gives NaN). */
+#define VIRNET_ABI_VERSION 4
 
 int virnet_abi_version(void);
 const char* virnet_last_error(void);

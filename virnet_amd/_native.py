@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VIRNET_HIP_LIB lets a tuning run point at another in-tree build of the same ABI (A/B kernel experiments)
 LIB_PATH = os.environ.get("VIRNET_HIP_LIB") or os.path.join(_HERE, "lib", "libvirnet_hip.so")
-ABI_VERSION = 3          # include/virnet_hip.h: VIRNET_ABI_VERSION
+ABI_VERSION = 4          # include/virnet_hip.h: VIRNET_ABI_VERSION
 
 c_float_p = C.POINTER(C.c_float)
 

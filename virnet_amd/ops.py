@@ -916,13 +916,19 @@ def scale_add(hcv: Tensor, gate: Tensor, skip: Tensor) -> Tensor:
 
 
 def _sft_weights(att) -> Tuple[nat.SftWeights, list]:
-    ps = [att.conv1.weight, att.conv1.bias, att.conv2.weight, att.conv2.bias, att.mul_conv.weight, att.mul_conv.bias,
-          att.add_conv.weight, att.add_conv.bias]
+    """The AttLayer's eight parameter pointers as the C struct -- cached on the layer and rebuilt when a parameter's storage or version
+    moved (the eager SISR forward built twelve of these per call: 527 `nn.Module.__getattr__` walks, tools/probes/host_profile_sisr.py)."""
+    c1, c2, cm, ca = att.conv1, att.conv2, att.mul_conv, att.add_conv
+    ps = (c1.weight, c1.bias, c2.weight, c2.bias, cm.weight, cm.bias, ca.weight, ca.bias)
+    key = tuple((p.data_ptr(), p._version) for p in ps)
+    hit = att.__dict__.get("_sftw")
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     ts = [p.detach() for p in ps]
     for t in ts:
         _dev_check(t, "AttLayer parameter")
-    wt = nat.SftWeights(*(nat.ptr(t) for t in ts), e=att.conv1.cin, nf1=att.conv1.cout, nf2=att.conv2.cout,
-                        nf=att.mul_conv.cout)
+    wt = nat.SftWeights(*(nat.ptr(t) for t in ts), e=c1.cin, nf1=c1.cout, nf2=c2.cout, nf=cm.cout)
+    att.__dict__["_sftw"] = (key, wt, ts)
     return wt, ts
 
 
