@@ -169,7 +169,10 @@ def test_bypass_conditions(monkeypatch):
             net(torch.zeros(1, 1, 32, 32, device="cuda"))                 # the eager path's input errors are unchanged
 
 
-def test_two_host_threads_have_their_own_graphs():
+def test_worker_threads_run_eagerly_beside_the_main_thread_s_graphs():
+    """Automatic capture is a MAIN-THREAD feature: two host threads that each capture, replay and drop graphs abort this torch / HIP build
+    (a graph destroyed from another thread than its capturer's, a pinned allocation beside another thread's capture:
+    tools/probes/capture_concurrency.py).  Worker threads get the eager forward -- same bits -- while the main thread keeps replaying."""
     net = _net()
     x = synth_images(1, 3, 40, 32).cuda()
     with torch.no_grad(), graph.no_autograph():
@@ -180,7 +183,7 @@ def test_two_host_threads_have_their_own_graphs():
         try:
             st = torch.cuda.Stream()
             with torch.no_grad(), torch.cuda.stream(st):
-                for _ in range(5):
+                for _ in range(6):
                     got = net(x)[0]
                     st.synchronize()
                     assert torch.equal(got, ref)
@@ -191,10 +194,14 @@ def test_two_host_threads_have_their_own_graphs():
     ts = [threading.Thread(target=work) for _ in range(2)]
     for t in ts:
         t.start()
+    with torch.no_grad():
+        for _ in range(6):                                       # the main thread captures and replays meanwhile
+            assert torch.equal(net(x)[0], ref)
     for t in ts:
         t.join()
     assert not errs, errs
-    assert all(s["graphs"] == 1 and s["replays"] == 3 for s in stats), stats
+    assert all(s == {"replays": 0, "graphs": 0, "reruns": 0} for s in stats), stats
+    assert graph.auto_stats(net)["graphs"] == 1 and graph.auto_stats(net)["replays"] == 4
 
 
 def test_a_knob_flipped_between_two_calls_of_one_shape_is_not_replayed_from_the_old_capture(monkeypatch):

@@ -210,7 +210,11 @@ def ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
 
-tls = threading.local()  # ops.forward_scope keeps its per-forward snapshot here (stream handle, environment knobs): one per host thread
+tls = threading.local()      # ops.forward_scope keeps its per-forward snapshot here (stream handle, environment knobs): one per host thread
+# Held by every hipGraph capture of this package (graph.py) and by the few host calls that HIP does not permit while ANY stream of the
+# process is capturing -- pinned-memory allocation, destruction of a captured graph -- even from another thread in thread-local capture
+# mode (tools/probes/capture_concurrency.py): one of those at the wrong moment invalidates the other thread's capture.
+capture_lock = threading.RLock()
 
 
 def stream_handle() -> int:

@@ -206,7 +206,7 @@ def guard_check_mode() -> str:
 
     * ``sync`` (default; the reference's semantics: what ``forward`` returns is final): one device -> host read at the end of the
       forward -- it waits for the forward, which a caller that consumes the outputs right away (every reference script) pays anyway.
-    * ``deferred`` (pipelined callers: serving loops, bench.py): NO host wait on the launch path.  The forward ends with
+    * ``deferred`` (pipelined callers: serving loops; bench.py times it beside the default): NO host wait on the launch path.  The forward ends with
       ``virnet_poison_on_flag`` on every output (an out-of-range forward is NaN on the device before the host has looked) and an
       asynchronous copy of the flag into pinned memory + an event; the NEXT guarded forward of the thread (or ``guard_poll()``) looks at
       the copies that have landed, and for an overflowed forward warns and repeats THAT input with the fp32 kernels into the SAME
@@ -290,7 +290,11 @@ def _range_guarded(run, x: Tensor):
         for o in outs:
             ops.poison_on_flag(flag, o)
         pool = _pinned_pool()
-        pinned = pool.pop() if pool else torch.zeros(1, dtype=torch.int32).pin_memory()
+        if pool:
+            pinned = pool.pop()
+        else:
+            with nat.capture_lock:        # (a pinned allocation beside another thread's hipGraph capture invalidates that capture)
+                pinned = torch.zeros(1, dtype=torch.int32).pin_memory()
         pinned.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

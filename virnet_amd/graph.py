@@ -63,7 +63,7 @@ def _install_hooks() -> None:
         _HOOKS.append(torch.nn.modules.module.register_module_module_registration_hook(_bump))
 
 
-_CAPTURE_LOCK = threading.Lock()
+_CAPTURE_LOCK = nat.capture_lock       # captures, every destruction of a captured graph, pinned allocations (see _native.capture_lock)
 
 
 def _env_stamp() -> int:
@@ -73,6 +73,24 @@ def _env_stamp() -> int:
     (The whole environment, not only VIRNET_*: 2 us for ~80 variables, against 9 us for filtering them.)"""
     data = getattr(os.environ, "_data", None)
     return hash(tuple(data.items())) if data is not None else hash(tuple(sorted(os.environ.items())))
+
+
+# A captured graph must never be DESTROYED while any stream of the process is capturing: HIP answers hipGraphExecDestroy with "operation not
+# permitted when stream is capturing" even from another thread in thread-local capture mode, torch raises that from ~CUDAGraph, and an
+# exception in a destructor ends the process (tools/probes/capture_concurrency.py reproduces it; a garbage-collection pass at the wrong
+# moment is enough).  So graphs are destroyed deliberately -- their last references dropped under _CAPTURE_LOCK, which every capture of this module holds --
+# and graphs whose owner simply went away (GraphedForward.__del__, possibly inside someone's capture) are parked here until the next safe point.
+_GRAVEYARD: list = []
+
+
+def _release(holder=None) -> None:
+    """Destroy the captured graphs of `holder` (a GraphedForward's key -> entry dict; emptied here) and whatever waits in the graveyard --
+    by dropping the last references while _CAPTURE_LOCK is held, i.e. not while a capture of this module runs.  (Not CUDAGraph.reset():
+    in this torch build a reset() graph fails its destructor's generator-state check -- "The graph should be registered to the state".)"""
+    with _CAPTURE_LOCK:
+        if holder is not None:
+            holder.clear()
+        del _GRAVEYARD[:]
 
 
 class RangeOverflow(RuntimeError):
@@ -135,21 +153,25 @@ class GraphedForward:
             for _ in range(self.warmup):              # packs weights, sets kernel attributes, fills the allocator pool
                 self.fn(static_x, *args)
         torch.cuda.current_stream().wait_stream(side)
-        pinned = torch.zeros(1, dtype=torch.int32).pin_memory() if flag is not None else None
-        graph = torch.cuda.CUDAGraph()
-        # (thread_local: launches and allocations of OTHER host threads -- each with its own graphs, see auto_forward -- do not invalidate
-        # this capture; captures themselves are serialised)
-        with _CAPTURE_LOCK, torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            if flag is not None:
-                flag.zero_()
-            out = self.fn(static_x, *args)
-            out = out if isinstance(out, tuple) else (out,)
-            if flag is not None:
-                for o in out:
-                    ops.poison_on_flag(flag, o)
-                if pinned is not None and self.check == "sync":
-                    pinned.copy_(flag, non_blocking=True)      # the flag travels to pinned memory as the graph's last node: the sync check
-                                                               # below waits for an event and reads host memory (no separate device -> host read)
+        # (thread_local: launches and device allocations of OTHER host threads -- each with its own graphs, see auto_forward -- do not
+        # invalidate this capture; what HIP does not tolerate beside a capture -- another capture, a pinned allocation, a graph's destruction --
+        # is serialised by the lock, which is held from the pinned allocation to the end of the capture)
+        with _CAPTURE_LOCK:
+            _sweep_registry()
+            _release()
+            pinned = torch.zeros(1, dtype=torch.int32).pin_memory() if flag is not None else None
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                if flag is not None:
+                    flag.zero_()
+                out = self.fn(static_x, *args)
+                out = out if isinstance(out, tuple) else (out,)
+                if flag is not None:
+                    for o in out:
+                        ops.poison_on_flag(flag, o)
+                    if pinned is not None and self.check == "sync":
+                        pinned.copy_(flag, non_blocking=True)  # the flag travels to pinned memory as the graph's last node: the sync check
+                                                               # waits for an event and reads host memory (no separate device -> host read)
         return graph, static_x, out, flag, pinned
 
     def poll(self) -> None:
@@ -169,7 +191,7 @@ class GraphedForward:
             self.poll()
         stamp = self._fingerprint()
         if stamp != self._stamp:
-            self._graphs.clear()                      # parameters changed: the packed weights baked into the launches are stale
+            _release(self._graphs)                  # parameters changed: the packed weights baked into the launches are stale
             self._seen.clear()
             self._stamp = stamp
         key = (tuple(x.shape), x.device.index, args, _env_stamp())
@@ -186,7 +208,8 @@ class GraphedForward:
                 hit = self._graphs[key] = self._capture(x, args)
             self._seen.pop(key, None)
             while self.max_graphs > 0 and len(self._graphs) > self.max_graphs:
-                self._graphs.popitem(last=False)
+                with _CAPTURE_LOCK:
+                    self._graphs.popitem(last=False)
         elif self.max_graphs > 0:
             self._graphs.move_to_end(key)
         graph, static_x, out, flag, pinned = hit
@@ -223,9 +246,16 @@ class GraphedForward:
 
     def reset(self) -> None:
         """Drop captured graphs (after a parameter write through ``.data``, which the version check cannot see)."""
-        self._graphs.clear()
+        _release(self._graphs)
         self._seen.clear()
         self._pending = None
+
+    def __del__(self):
+        # (no lock, no HIP call here: this may run inside a garbage-collection pass in the middle of a capture)
+        try:
+            _GRAVEYARD.extend(self._graphs.values())      # (whole entries: the graph AND the buffers of its private pool)
+        except Exception:          # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -252,6 +282,24 @@ class no_autograph:
         return False
 
 
+# Every automatic GraphedForward is also held by this process-wide registry, so that its graphs are never destroyed as a side effect of a
+# host thread ending (its threading.local goes away inside the dying thread) or of a module being collected (whichever thread runs the GC):
+# a hipGraph and its private pool torn down while ANOTHER thread is capturing aborts the process (seen once in ~3 runs of the two-thread test).
+# Entries of dead threads / dead modules are swept -- graphs dropped -- by the next capture, under the capture lock.
+_REGISTRY: list = []          # (weakref to the module, the owning threading.Thread, the GraphedForward)
+_REGISTRY_LOCK = threading.Lock()
+
+
+def _sweep_registry() -> None:
+    """Called with _CAPTURE_LOCK held: drop the graphs of owners that are gone."""
+    with _REGISTRY_LOCK:
+        dead = [e for e in _REGISTRY if e[0]() is None or not e[1].is_alive()]
+        for e in dead:
+            _REGISTRY.remove(e)
+    for _, _, gf in dead:
+        gf.reset()
+
+
 def _auto_state(module, fn) -> GraphedForward:
     per_thread = getattr(nat.tls, "autograph", None)
     if per_thread is None:
@@ -262,13 +310,21 @@ def _auto_state(module, fn) -> GraphedForward:
         gf = per_thread[module] = GraphedForward(lambda x, *a: fn(ref(), x, *a), warmup=1, params=lambda: ref().parameters(),
                                                  check="sync", auto_after=AUTO_AFTER, fresh=True,
                                                  max_graphs=int(ops._env("VIRNET_AUTOGRAPH_MAX_GRAPHS", "8")))
+        with _REGISTRY_LOCK:
+            _REGISTRY.append((ref, threading.current_thread(), gf))
     return gf
 
 
 def auto_forward(module, fn: Callable, x: torch.Tensor, *args, scale: int = 1):
     """``fn(module, x, *args)`` -- eagerly, or from the (module, thread)'s captured graph once the same call has been seen AUTO_AFTER
     times.  ``scale``: output pixels per input pixel side (the SISR forward's sf) for the size bound."""
-    if (getattr(nat.tls, "autograph_off", 0) or ops._env("VIRNET_AUTOGRAPH", "1") == "0" or ops._TIMER is not None
+    # MAIN THREAD ONLY.  Two host threads that each capture, replay and drop graphs bring this torch / HIP build down: a captured graph destroyed
+    # from another thread than its capturer's fails ~CUDAGraph's generator-state check, a pinned allocation or a graph's destruction beside
+    # another thread's capture invalidates that capture -- and both end in an exception thrown from a destructor, i.e. process abort
+    # (tools/probes/capture_concurrency.py; it aborted one full-suite run in three).  Worker threads therefore run the eager forward; the
+    # capture lock and the graveyard below keep the main thread's graphs away from what the other threads do.
+    if (threading.current_thread() is not threading.main_thread()
+            or getattr(nat.tls, "autograph_off", 0) or ops._env("VIRNET_AUTOGRAPH", "1") == "0" or ops._TIMER is not None
             or not isinstance(x, torch.Tensor) or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32
             or x.shape[0] * x.shape[2] * x.shape[3] * scale * scale > int(ops._env("VIRNET_AUTOGRAPH_MAX_PIXELS", str(1 << 19)))
             or ops._env("VIRNET_GUARD_CHECK", "sync") != "sync" or torch.cuda.is_current_stream_capturing()):
