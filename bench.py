@@ -239,8 +239,10 @@ def main():
                     "block (BASELINE configs[1], [3], [4] timed by child runs of this script)")
     ap.add_argument("--dry-run-topology", action="store_true", help="multi-GPU pre-flight (no timed steps): every rank reports its device UUID, "
                     "the run FAILS if two ranks share a device although enough devices are visible, the start-up weight broadcast is timed on its own")
-    ap.add_argument("--guard", default="deferred", choices=["sync", "deferred"], help="range-guard check of the timed forwards (engine.guard_check_mode): "
-                    "deferred = no host wait per forward, outputs NaN-poisoned on overflow, every forward checked (guard_poll) before the clock stops")
+    ap.add_argument("--guard", default="sync", choices=["sync", "deferred"], help="range-guard check of the timed forwards (engine.guard_check_mode): "
+                    "sync (default since round 6: the product's default -- one flag read at the end of every forward) or deferred (round 5's headline mode: "
+                    "no host wait per forward, outputs NaN-poisoned on overflow, every forward checked by guard_poll before the clock stops); the OTHER mode is "
+                    "timed right behind the headline region and reported in `other_guard_mode` / `summary.guard`")
     args = ap.parse_args()
     sisr = args.task in ("sisr", "train_sisr")
     training = args.task in ("train", "train_sisr")
