@@ -394,14 +394,18 @@ def main():
     if not training:
         os.environ["VIRNET_GUARD_CHECK"] = args.guard      # (inference forwards; the training step's forward is one autograd Function with its own check)
     with torch.set_grad_enabled(training):
+        # (everything the timed region needs is built BEFORE the warm-up steps: the sampler's sysfs look-ups took tens of milliseconds between
+        # the last warm-up step and the first timed one -- long enough for the socket to leave its clock, and the first timed steps then ran on
+        # the ramp again: 1 366 W / 1 524 img/s in the contract's region against 1 391 W / 1 559 img/s in the region timed right behind it)
+        timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
+        psamp = PowerSampler(dev.index)                       # (every rank samples ITS device: a throttling rank must be visible in `multi_gpu.per_rank`)
         for _ in range(args.warmup):
             fwd(x)
         engine.guard_poll()
-        timer = ops.LaunchTimer() if (rank == 0 and not args.no_roofline) else None
         torch.cuda.synchronize()
         barrier()
         ops.set_launch_timer(timer)     # two event records per conv launch, on the launch stream (~us of host time each)
-        with PowerSampler(dev.index) as psamp:                # (every rank samples ITS device: a throttling rank must be visible in `multi_gpu.per_rank`)
+        with psamp:
             t0 = time.perf_counter()
             c0 = time.thread_time()
             for _ in range(args.steps):
