@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
   // The last chunk re-reads itself and rewrites its own dead planes: no branch in the stage code.  The end-of-stage wait of stage 0
   // leaves the pixel loads in flight: s_waitcnt vmcnt(pixel loads) covers the DMA pieces, which are issued before them.
   constexpr int NPX = 12;                           // VMEM instructions of one chunk's pixel loads (the SFT vectors come from LDS)
-#ifdef VIRNET_F16_TIMING
+#if defined(VIRNET_F16_TIMING) && !defined(VIRNET_TIMING_LIGHT)      // (LIGHT: only the four TSTAMPs per workgroup -- the per-group stamps cost ~5 % of a tile)
   long long wx_tg[3][10] = {};
 #endif
   // The stages of the LAST chunk (fin) have no next chunk to stage: stage 0 only finishes positions {2,5}, stages 1 and 2 read and
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #if WX4_LEDGER & 32
     auto ldp = [&](auto) {}; auto ldh = [&](auto) {};
 #endif
-#ifdef VIRNET_F16_TIMING
+#if defined(VIRNET_F16_TIMING) && !defined(VIRNET_TIMING_LIGHT)      // (LIGHT: only the four TSTAMPs per workgroup -- the per-group stamps cost ~5 % of a tile)
     long long wx_tprev = (long long)__builtin_amdgcn_s_memtime();
 #define WX_TS(g) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); if ((g) < 9) wx_tg[ji][(g)] += t_ - wx_tprev; wx_tprev = t_; } while (0)
 #else
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
     else if constexpr (ji == 2 && fin) __builtin_amdgcn_s_waitcnt(WAIT_LDS);
     else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
     asm volatile("s_barrier" ::: "memory");
-#ifdef VIRNET_F16_TIMING
+#if defined(VIRNET_F16_TIMING) && !defined(VIRNET_TIMING_LIGHT)      // (LIGHT: only the four TSTAMPs per workgroup -- the per-group stamps cost ~5 % of a tile)
     wx_tg[ji][9] += (long long)__builtin_amdgcn_s_memtime() - wx_tprev;       // tail slot + waits + barrier
 #endif
 #undef WX_TS
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4_kernel(const FArgs a) {
 #if WX4_LEDGER & 128
   return;
 #endif
-#ifdef VIRNET_F16_TIMING
+#if defined(VIRNET_F16_TIMING) && !defined(VIRNET_TIMING_LIGHT)      // (LIGHT: only the four TSTAMPs per workgroup -- the per-group stamps cost ~5 % of a tile)
   if (a.tlog && (tid & 63) == 0) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -1012,8 +1012,8 @@ static int conv_wx4_impl(const virnet_conv_desc* d, void* stream, const virnet_t
     if (nrep == 5 || half_tiles_for(nrep, groups)) { note(8, 0, nrep); return virnet::launch_wx4h(kk, nrep, epi, pre, st); }
     // 16-row tiles, persistent form (conv_f16_wx4p.hip, round 6: one workgroup per CU walks its XCD's items, the next item's first chunk is
     // staged by the last chunk's stages, the epilogue's exchange leaves V and weight buffer 0 alone).  BUILT, bit-identical, and measured:
-    // 12 % fewer cycles per tile under load (70.4 k against 80.1 k), and 2 % MORE time per launch / 1.7 % fewer images per second end to end --
-    // at the 1400 W cap the clock gives the cycles back (profiles/r06_probes.md 2).  Therefore opt-in: VIRNET_WX4_PERSIST=1, for launches of
+    // no prologue (10.9 k of a tile's 71.4 k cycles), and 2-3 % MORE time per launch / 1.7 % fewer images per second end to end: with every CU
+    // streaming all the time each stage takes 6 % longer (profiles/r06_probes.md 2).  Therefore opt-in: VIRNET_WX4_PERSIST=1, for launches of
     // at least VIRNET_WX4_PERSIST_MIN (default 2) items per CU.
     {
       const char* const pe = getenv("VIRNET_WX4_PERSIST");

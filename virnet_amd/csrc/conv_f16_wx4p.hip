@@ -2,11 +2,11 @@
 //
 // Same call sites (AttResBlock.conv1/conv2, networks/AttResUNet.py:43,46,55,58), same tile (16 x 32 pixels x 96 channels, 8 waves, one
 // workgroup per CU), same K loop -- the generated stage schedules of conv_f16_wx4_sched.inc are used unchanged -- and the same arithmetic in
-// the same order: results are BIT FOR BIT those of conv_wx4_kernel (tests/test_conv_wx4_gpu.py).  What changes is what happens between two
+// the same order: results are BIT FOR BIT those of conv_wx4_kernel (tests/test_conv_wx4p_gpu.py).  What changes is what happens between two
 // tiles.  conv_wx4_kernel runs one (tile, channel block) item per workgroup: a prologue (requests 2.3 k cycles after the start, pixels back and
 // first position staged at 5.5 k, V written and the barrier passed at 9.5 k) and an epilogue whose LDS exchange (24 blocks, 112 KB) lies on
-// top of V and both weight buffers, so nothing of the next tile can exist on the CU before the last store has left -- 9.5 of a tile's 77 k
-// cycles with an idle matrix pipe in front of every K loop (profiles/r03_probes.md 3).  Here
+// top of V and both weight buffers, so nothing of the next tile can exist on the CU before the last store has left -- 10.9 of a tile's 71.4 k
+// cycles under load in front of every K loop (profiles/r06_probes.md 2).  Here
 //   * a workgroup is PERSISTENT: one per CU, it walks every wgs_per_xcd-th item of its XCD's contiguous item range; weights descriptor,
 //     scale / bias table, thread constants are set up once;
 //   * the K loop simply CONTINUES across items: the stages of an item's LAST chunk stage the NEXT item's first chunk (pixel requests in
@@ -20,6 +20,9 @@
 // LDS: V [0, 54 KB) | U0 [54, 90 KB) | U1 [90, 126 KB) with exchange buffer A on its upper 27.4 KB | exchange buffer B [126, 153.4 KB) |
 // [inverse scale | bias] of every channel block of the launch (<= 2.3 KB).  U1 is dead from the last stage's barrier to the first DMA of the
 // next item's stage 0, which is issued behind the barrier that closes the last read of buffer A.
+// MEASURED (profiles/r06_probes.md 2): the prologue is gone and paid back -- with all 256 CUs streaming all the time every stage takes 6 % longer,
+// the last chunk's stages and the quarter-pipelined exchange cost the rest: 69.2 k per item against 71.4 k per tile (conv2-type 80.2 k
+// against 77.0 k), the slowest fixed 16-item walk 4-5 % above the median, +2...3 % per launch.  Opt-in (VIRNET_WX4_PERSIST=1).
 // Residual / mask tiles (EPI 1 / 2): one slab (8 items) ahead in two register sets; gfx950 counts loads and stores on ONE vmcnt, so a wait
 // for a tile is also a wait for every store issued before it -- the wait is therefore placed explicitly in front of a phase's stores, when
 // the youngest outstanding store is a whole phase old (conv_f16.hip, profiles/r02_probes.md).
