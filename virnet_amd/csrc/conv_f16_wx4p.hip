@@ -317,13 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4p_kernel(const FArgs a, const 
               + (unsigned)((hrow_ * 8 + hxt_) * 32 + ((((hch_ >> 3) ^ (hrow_ & 1))) << 4) + (hch_ & 7) * 2);
   };
 
-  f32x16 acc[3][NREP];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int nr = 0; nr < NREP; ++nr)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][nr][r] = 0.f;
+  f32x16 acc[3][NREP];                              // (never cleared: the first product of every item into a block takes a zero C operand)
 
   // ---- the workgroup's ONE prologue: table of every channel block, weights of the first item's stage 0, its chunk 0 -> positions {0,3},
   // {1,4} ({2,5} are written by stage 0 itself)
@@ -390,7 +384,10 @@ __global__ __launch_bounds__(512, 2) void conv_wx4p_kernel(const FArgs a, const 
       constexpr int dy = g / NREP, nr = g - dy * NREP;
       const h8 wa = part == 0 ? al[g] : ah[g];
       const h8 xv = part == 1 ? bl[dy] : bh[dy];
-      acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
+      // an item's FIRST product into each accumulator block starts from zero (inline constant as the C operand) instead of from a block the
+      // epilogue had to clear: 144 v_mov per wave and item left the exchange's writer phases (round 6, second pass)
+      if constexpr (first && dy == 0 && part == 0) acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, f32x16{}, 0, 0, 0);
+      else acc[ji][nr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xv, acc[ji][nr], 0, 0, 0);
     };
 #define WX_TS(g) do { } while (0)
 #define WX_STAGE_CASE(N_, J_, P_) if constexpr (NREP == N_ && ji == J_ && PRE == P_ && !(J_ == 0 && first)) { WX4_STAGE_##N_##_##J_##_##P_ }
@@ -478,8 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv_wx4p_kernel(const FArgs a, const 
     };
     // writer: wave (jt, rb) writes three pre-combined blocks of slab nr into the buffer of quarter rb
     //   jt = 0: A0 = M0+M1+M2, A1 = M1-M2, A2 = M1+M2        jt = 1: S = M3+M4, D = M3-M4, E = M5
-    // and pixel k of an x-tile is  k=0: A0 + S   k=1: A1 + 2D   k=2: A2 + 4S   k=3: A1 + 8D + E   (rows of AT); its accumulators are
-    // cleared for the next item on the way out.
+    // and pixel k of an x-tile is  k=0: A0 + S   k=1: A1 + 2D   k=2: A2 + 4S   k=3: A1 + 8D + E   (rows of AT).
     const int wblk = (jt * 3) * WX_XBLK + l31_e * 144 + lhi_e * 16;
     // (four accumulator registers at a time, each branch storing its own blocks: no 48-register set of pre-combined values, no phi copies)
     auto xwrite = [&](int nr, char* xb) {
@@ -502,10 +498,6 @@ __global__ __launch_bounds__(512, 2) void conv_wx4p_kernel(const FArgs a, const 
           *reinterpret_cast<f32x4*>(xb + wblk + 2 * WX_XBLK + g * 32) = m2;
         }
       }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][nr][r] = 0.f;
     };
     const int pk = px & 3, pxt = px >> 2;
     const int r_p = ((pk == 0) ? 0 : (pk == 2) ? 2 : 1) * WX_XBLK + pxt * 144 + cq * 16;
