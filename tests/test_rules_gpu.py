@@ -3,7 +3,7 @@ a bitwise-equality test, none a test that it chooses well.  tools/probes/rule_ch
 500 x 500 / 256 x 256 / 128 x 128 image (scripts/denoising_virnet_syn.py:133-134, scripts/testing_demo.py:87-93), every form the library could
 take (captured graphs of 20 launches, interleaved rounds, medians) beside the default rule's pick.  The probe's own bar is 3 % + 0.5 us
 (profiles/r06_rule_check.log: 23 of 24 shapes; 64 x 64 x 288 conv2 is 4-5 % behind the 8-row Winograd form, a pick the end-to-end A/B of
-round 4 did not reward); this test allows 6 % + 0.5 us so that box noise does not fail the suite while a rule that picks a 20 % slower form does."""
+round 4 did not reward); this test allows 10 % + 0.5 us so that box noise does not fail the suite while a rule that picks a 20 % slower form does."""
 import json
 import os
 import subprocess
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def test_default_rules_pick_a_form_within_a_few_percent_of_the_best(tmp_path):
     out = tmp_path / "rule_check.json"
     env = {k: v for k, v in os.environ.items() if not k.startswith("VIRNET_") or k == "VIRNET_HIP_LIB"}
-    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "probes", "rule_check.py"), "--rounds", "7", "--tol", "0.06", "--json", str(out)],
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "probes", "rule_check.py"), "--rounds", "7", "--tol", "0.10", "--json", str(out)],
                        capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
     rows = json.loads(out.read_text())
     assert len(rows) == 24, p.stdout[-2000:] + p.stderr[-2000:]
