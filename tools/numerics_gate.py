@@ -14,6 +14,7 @@ run of the same network.  The emulations are exact models of what the matrix pip
   f16x4      the same plus lo*lo
   f16x3_ftz  f16x3 with fp16 subnormals flushed to zero (what a pipe without fp16 denormal support would do)
   wx4        the shipped kernel (conv_f16_wx4.hip): F(4,3) along x, direct along y, split-fp16 position products
+  wx6        F(6,3) along x, direct along y (8 positions per 6 outputs: 1.33 executed FLOP per algorithmic one), split-fp16 products
   w42        the MIXED 2-D form VERDICT r05 next #6 asks to be priced: F(4,3) along x and F(2,3) along y, split-fp16 position products
              (6 x 4 = 24 positions per 4 x 2 outputs: 1.0 executed FLOP per algorithmic FLOP with three products, against wx4's 1.5)
 
@@ -71,6 +72,15 @@ def wino_mats(m):
     if m == 1:      # "F(1,3)": the direct form written as a transform (identity in, three taps summed out)
         eye = torch.eye(3, dtype=torch.float64)
         return eye, eye, torch.ones(1, 3, dtype=torch.float64)
+    if m == 6:      # F(6,3), points 0, +-1, +-2, +-1/2, inf (Lavin & Gray): 8 positions per 6 outputs
+        BT = torch.tensor([[1, 0, -21 / 4, 0, 21 / 4, 0, -1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0], [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0],
+                           [0, 1 / 2, 1 / 4, -5 / 2, -5 / 4, 2, 1, 0], [0, -1 / 2, 1 / 4, 5 / 2, -5 / 4, -2, 1, 0],
+                           [0, 2, 4, -5 / 2, -5, 1 / 2, 1, 0], [0, -2, 4, 5 / 2, -5, -1 / 2, 1, 0], [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1]], dtype=torch.float64)
+        G = torch.tensor([[1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45], [1 / 90, -1 / 45, 2 / 45],
+                          [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1]], dtype=torch.float64)
+        AT = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, -1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 1 / 4, 0],
+                           [0, 1, -1, 8, -8, 1 / 8, -1 / 8, 0], [0, 1, 1, 16, 16, 1 / 16, 1 / 16, 0], [0, 1, -1, 32, -32, 1 / 32, -1 / 32, 1]], dtype=torch.float64)
+        return BT, G, AT
     if m == 2:
         BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
         G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
@@ -146,6 +156,8 @@ def make_conv(mode):
             y = conv_wino(x, w, 2 if mode.startswith("wino2") else 4, split=mode.endswith("f16x3"))
         elif mode in ("wx4", "w42", "wx4_f32", "w42_f32"):
             y = conv_wino_xy(x, w, 1 if mode.startswith("wx4") else 2, 4, split=not mode.endswith("f32"))
+        elif mode in ("wx6", "wx6_f32"):      # F(6,3) along x, direct along y: 24 instead of 27 k-steps per 6 output pixels (1.33 executed per algorithmic FLOP)
+            y = conv_wino_xy(x, w, 1, 6, split=not mode.endswith("f32"))
         elif mode in ("bf16x3", "bf16x6"):
             parts = 2 if mode == "bf16x3" else 3
             xs, ws = split_bf16(x, parts), split_bf16(w, parts)
